@@ -1,0 +1,201 @@
+/*
+ * mi355mc.h -- C ABI of libmi355mc.so, the MI355X (gfx950) Monte Carlo
+ * guess-number engine behind kofny/MonteCarlo's lib4mc plugin surface.
+ *
+ * Plain pointers and sizes only.  "device" pointers are HIP device memory of
+ * the GPU that is current on the calling thread (e.g. torch tensors'
+ * data_ptr()); "host" pointers are ordinary memory.  `stream` is a hipStream_t
+ * passed as void* (NULL = the default stream).  Every call returns MC_OK (0) or
+ * a negative mc_status; mc_last_error() gives the text for the calling thread.
+ * Launch calls are asynchronous on `stream`; none of them allocates or frees
+ * device memory (the caller brings outputs and workspaces).
+ *
+ * Each entry point names the reference interface (file:line under
+ * /root/reference) whose inside it replaces.  INTEGRATION.md shows the ctypes
+ * stubs a maintainer adds to the reference to bind them.
+ */
+#ifndef MI355MC_H
+#define MI355MC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MC_ABI_VERSION 1
+
+typedef enum mc_status {
+    MC_OK = 0,
+    MC_ERR_ARG = -1,          /* bad argument (null pointer, size mismatch, unknown kind) */
+    MC_ERR_TABLE = -2,        /* table violates an assumption the compiler checks (message says which) */
+    MC_ERR_HIP = -3,          /* a HIP runtime call failed */
+    MC_ERR_NOMEM = -4,
+    MC_ERR_DIVERGED = -5,     /* a sample hit max_draws without reaching the end symbol */
+    MC_ERR_WORKSPACE = -6     /* workspace too small */
+} mc_status;
+
+/* Context rule of the model (which `_get_prefix` it restates). */
+enum {
+    MC_KIND_NGRAM = 1,   /* nwords_simulator.py:30-34: context = last `order` symbols (exact row required) */
+    MC_KIND_BACKOFF = 2, /* backwords_simulator.py:28-41: longest suffix of the history that is a row */
+    MC_KIND_V2 = 3       /* nwords_simulator_v2.py:65-68: context = last `order` CHARACTERS; transitions are words */
+};
+
+enum {
+    MC_FLAG_KEEP_LEN_ON_RESTART = 1u /* nwords_simulator_v2.py:73-81: pwd_len is not reset on restart */
+};
+
+#define MC_NONE 0xFFFFFFFFu  /* "no row" / unknown symbol id */
+
+/*
+ * A trained model in the reference's own terms, flattened by the caller:
+ * what `expand_2d(trainer(...))` holds (lib4mc/ProbLib.py:10-28), row by row in
+ * dict order.  Row r has context units ctx_units[ctx_off[r] .. ctx_off[r+1])
+ * and entries [row_off[r], row_off[r+1]); entry e is transition symbol
+ * ent_sym[e] with ent_cum[e] = the row's sequential fp64 cumulative sum up to
+ * and including e (exactly numpy's cumsum, ProbLib.py:23) and ent_ml2p[e] =
+ * -log2(p) as the reference's minus_log2 computes it (MonteCarloParent.py:13).
+ * All pointers are host memory and are only read during mc_table_compile.
+ */
+typedef struct mc_model_desc {
+    uint32_t kind;          /* MC_KIND_* */
+    uint32_t order;         /* n-1 for NGRAM / V2; ignored for BACKOFF */
+    uint32_t n_ctx;
+    uint32_t n_sym;         /* number of transition symbol ids */
+    uint64_t n_ent;
+    const uint32_t *ctx_off;      /* [n_ctx+1] */
+    const uint32_t *ctx_units;    /* [ctx_off[n_ctx]] */
+    const uint64_t *row_off;      /* [n_ctx+1] */
+    const uint32_t *ent_sym;      /* [n_ent] */
+    const double *ent_cum;        /* [n_ent] */
+    const double *ent_ml2p;       /* [n_ent] */
+    const uint32_t *sym_unit_off; /* [n_sym+1] or NULL: context units a symbol appends (NULL: the symbol itself) */
+    const uint32_t *sym_units;
+    const uint32_t *sym_chars;    /* [n_sym] len(symbol) in characters, or NULL: all 1 */
+    const uint32_t *start_units;  /* initial history (n-1 start symbols; one for BACKOFF; none for V2) */
+    uint32_t n_start;
+    uint32_t end_sym;       /* transition symbol id of end_chr */
+    uint32_t min_len;       /* accept a sample iff pwd_len >= min_len (nwords_simulator.py:101; v2 `> 3`) */
+    uint32_t max_len;       /* restart when pwd_len >= max_len (nwords_simulator.py:112): 256 */
+    uint32_t flags;         /* MC_FLAG_* */
+    uint32_t guide_factor;  /* guide buckets per row ~ guide_factor * row length, rounded up to 2^k (0 -> 2) */
+} mc_model_desc;
+
+typedef struct mc_table mc_table; /* compiled table, host memory */
+typedef struct mc_model mc_model; /* compiled table resident on one GPU */
+
+int mc_abi_version(void);
+const char *mc_last_error(void);
+
+/* ---- table compiler (host only; runs without a GPU) --------------------------------------
+ * Replaces the per-call dict/tuple work of `_get_prefix` (nwords_simulator.py:30-34,
+ * backwords_simulator.py:28-41) and `pick_expand`'s bisect (lib4mc/ProbLib.py:31-43) by
+ * precomputed arrays: per-entry next-state links, per-row parent (backoff) links, an exact
+ * guide table for the inverse-CDF draw, an open-addressed (row,symbol)->entry hash and an
+ * open-addressed 64-bit context-hash -> row index.
+ */
+int mc_table_compile(const mc_model_desc *desc, mc_table **out);
+void mc_table_free(mc_table *t);
+
+/* Introspection of a compiled table (used by tests and by the host classes): copies of the
+ * flat arrays.  `what` names the array; returns its byte size, copies at most `cap` bytes. */
+enum {
+    MC_ARR_STATE = 0,    /* mc_state_rec[n_ctx] */
+    MC_ARR_GUIDE = 1,    /* uint32[] */
+    MC_ARR_CUM = 2,      /* double[n_ent] */
+    MC_ARR_PAYLOAD = 3,  /* mc_payload[n_ent] */
+    MC_ARR_TRANS = 4,    /* mc_slot[trans_cap]: key = row<<32|sym, val = entry */
+    MC_ARR_CTXHASH = 5,  /* mc_slot[ctx_cap]: key = 64-bit context hash, val = row */
+    MC_ARR_SYMCHARS = 6  /* uint32[n_sym] */
+};
+int64_t mc_table_array(const mc_table *t, int what, void *dst, size_t cap);
+/* start state, end symbol, root (zero-gram) row, table sizes ... as 16 uint64 (see mc_table_info_idx) */
+int mc_table_info(const mc_table *t, uint64_t info[16]);
+enum {
+    MC_INFO_NCTX = 0, MC_INFO_NENT = 1, MC_INFO_NSYM = 2, MC_INFO_START_STATE = 3, MC_INFO_ROOT = 4,
+    MC_INFO_TRANS_CAP = 5, MC_INFO_CTX_CAP = 6, MC_INFO_GUIDE_LEN = 7, MC_INFO_DEVICE_BYTES = 8,
+    MC_INFO_MAX_ROW = 9, MC_INFO_KIND = 10, MC_INFO_MULTICHAR = 11
+};
+/* 64-bit hash of a context (sequence of unit ids) as stored in the context index. */
+uint64_t mc_ctx_hash(const uint32_t *units, uint32_t n);
+
+/* Flat record layouts (also the device layouts). */
+typedef struct mc_state_rec {
+    double total;       /* cum[last] of the row: random.uniform(0, total), ProbLib.py:40-41 */
+    uint32_t ent_off;   /* first entry of the row */
+    uint32_t len;       /* entries in the row */
+    uint32_t guide_off; /* first guide word of the row */
+    uint32_t gbits;     /* log2(guide buckets) */
+    uint32_t parent;    /* longest proper suffix that is a row (BACKOFF), else MC_NONE */
+    uint32_t ctx_len;   /* context length in units */
+} mc_state_rec;
+
+typedef struct mc_payload {
+    double ml2p;        /* -log2 p of the entry */
+    uint32_t next;      /* state after taking the entry (MC_NONE: no such row) */
+    uint32_t sym;       /* transition symbol id; bit 31 set on the end symbol */
+} mc_payload;
+
+typedef struct mc_slot {
+    uint64_t key;       /* ~0 = empty */
+    uint32_t val;
+    uint32_t pad;
+} mc_slot;
+
+/* ---- device residency ---------------------------------------------------------------------*/
+/* Uploads the compiled table to GPU `device` (one hipMalloc arena). */
+int mc_model_upload(const mc_table *t, int device, mc_model **out);
+void mc_model_destroy(mc_model *m);
+/* Synchronises `stream`, reads and clears the model's device status words.  Returns
+ * MC_ERR_DIVERGED if any sample since the last check exhausted its draws.  counters (may be
+ * NULL) receives {draws, cdf_probes, restarts, failed_samples, score_probes, ...} (8 words). */
+int mc_model_check(mc_model *m, void *stream, uint64_t counters[8]);
+
+/* ---- sampling: MonteCarlo.sample, lib4mc/MonteCarloParent.py:33-46, whose loop body is
+ * sample1 (nwords_simulator.py:92-116 / nwords_simulator_v2.py:60-82) + pick_expand
+ * (lib4mc/ProbLib.py:31-43).  Sample ids [first_id, first_id+count) use the Philox4x32-10
+ * stream (seed, id, draw) -> 53-bit uniform defined in oracle/philox.py; results do not
+ * depend on launch geometry.  Outputs (device): out_ml2p[count]; optional out_len[count]
+ * (symbols emitted), out_draws[count] (uniforms consumed, restarts included), and
+ * out_syms[count*sym_stride] (symbol ids; samples longer than sym_stride are truncated
+ * there, out_len still reports the full length). */
+int mc_sample(mc_model *m, uint64_t first_id, uint64_t count, uint64_t seed, uint32_t max_draws,
+              double *out_ml2p, uint32_t *out_len, uint32_t *out_draws, uint32_t *out_syms,
+              uint32_t sym_stride, void *stream);
+
+/* Same walk with caller-injected uniforms (parity mode: "same injected uniform stream ->
+ * bit-identical strings").  Sample i consumes uniforms[i*draws_per_sample + k], k = 0,1,...;
+ * a sample that needs more than draws_per_sample is reported failed (ml2p = NaN). */
+int mc_sample_injected(mc_model *m, uint64_t count, const double *uniforms, uint32_t draws_per_sample,
+                       double *out_ml2p, uint32_t *out_len, uint32_t *out_draws, uint32_t *out_syms,
+                       uint32_t sym_stride, void *stream);
+
+/* ---- scoring: calc_ml2p over a batch (MonteCarloParent.py:62-67 calling
+ * nwords_simulator.py:36-60,84-90 / backwords_simulator.py:43-49), single-symbol alphabets
+ * (every word is one character: exactly one parse).  Password t is the symbol ids
+ * syms[off[t] .. off[t+1]) (MC_NONE for a character outside the model); the end symbol is
+ * appended by the kernel.  out_ml2p[t] = sum of -log2 p in order, or 1022.0 when there is
+ * no parse (nwords_simulator.py:85). */
+int mc_score(mc_model *m, const uint32_t *syms, const uint64_t *off, uint64_t count, double *out_ml2p,
+             void *stream);
+
+/* ---- rank estimation: MonteCarloLib.__init__ (lib4mc/MonteCarloLib.py:10-28): sort the
+ * sampled -log2 p ascending, positions = cumsum(2^(key - log2 n_global)).  keys_sorted and
+ * positions are outputs [n]; keys_in is left untouched.  n_global = total samples over all
+ * GPUs (= n on one GPU): each shard weights with the global n so that per-shard results add. */
+size_t mc_rank_workspace_bytes(uint64_t n);
+int mc_rank_build(const double *keys_in, uint64_t n, uint64_t n_global, double *keys_sorted, double *positions,
+                  void *workspace, size_t workspace_bytes, void *stream);
+
+/* ml2p2rank (lib4mc/MonteCarloLib.py:30-32) for t queries: cnt = bisect_right(keys_sorted, x),
+ * pos = positions[cnt-1] or 0.0 when cnt == 0 (the caller maps a global cnt of 0 to the
+ * reference's `1`, after summing shards). */
+int mc_rank_query(const double *keys_sorted, const double *positions, uint64_t n, const double *x, uint64_t t,
+                  double *out_pos, uint64_t *out_cnt, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355MC_H */

@@ -1,0 +1,86 @@
+"""ctypes binding of libmi355mc.so (include/mi355mc.h).
+
+There is no fallback: if the library is missing the import fails loudly, so a
+product path can never silently run on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355mc.so")
+
+MC_NONE = 0xFFFFFFFF
+KIND_NGRAM, KIND_BACKOFF, KIND_V2 = 1, 2, 3
+FLAG_KEEP_LEN_ON_RESTART = 1
+(ARR_STATE, ARR_GUIDE, ARR_CUM, ARR_PAYLOAD, ARR_TRANS, ARR_CTXHASH, ARR_SYMCHARS) = range(7)
+(INFO_NCTX, INFO_NENT, INFO_NSYM, INFO_START_STATE, INFO_ROOT, INFO_TRANS_CAP, INFO_CTX_CAP, INFO_GUIDE_LEN,
+ INFO_DEVICE_BYTES, INFO_MAX_ROW, INFO_KIND, INFO_MULTICHAR) = range(12)
+ERR_DIVERGED = -5
+
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+f64p = C.POINTER(C.c_double)
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_uint32), ("order", C.c_uint32), ("n_ctx", C.c_uint32), ("n_sym", C.c_uint32),
+        ("n_ent", C.c_uint64),
+        ("ctx_off", u32p), ("ctx_units", u32p), ("row_off", u64p), ("ent_sym", u32p),
+        ("ent_cum", f64p), ("ent_ml2p", f64p),
+        ("sym_unit_off", u32p), ("sym_units", u32p), ("sym_chars", u32p),
+        ("start_units", u32p), ("n_start", C.c_uint32),
+        ("end_sym", C.c_uint32), ("min_len", C.c_uint32), ("max_len", C.c_uint32), ("flags", C.c_uint32),
+        ("guide_factor", C.c_uint32),
+    ]
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libmi355mc error {code}: {msg}")
+        self.code = code
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m montecarlo_amd.build` (hipcc, gfx950). "
+            "montecarlo_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    sig = {
+        "mc_abi_version": (C.c_int, []),
+        "mc_last_error": (C.c_char_p, []),
+        "mc_table_compile": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(vp)]),
+        "mc_table_free": (None, [vp]),
+        "mc_table_array": (C.c_int64, [vp, C.c_int, vp, C.c_size_t]),
+        "mc_table_info": (C.c_int, [vp, u64p]),
+        "mc_ctx_hash": (C.c_uint64, [u32p, C.c_uint32]),
+        "mc_model_upload": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
+        "mc_model_destroy": (None, [vp]),
+        "mc_model_check": (C.c_int, [vp, vp, u64p]),
+        "mc_sample": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, vp, vp, vp, vp, C.c_uint32, vp]),
+        "mc_sample_injected": (C.c_int, [vp, C.c_uint64, vp, C.c_uint32, vp, vp, vp, vp, C.c_uint32, vp]),
+        "mc_score": (C.c_int, [vp, vp, vp, C.c_uint64, vp, vp]),
+        "mc_rank_workspace_bytes": (C.c_size_t, [C.c_uint64]),
+        "mc_rank_build": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, vp, vp, C.c_size_t, vp]),
+        "mc_rank_query": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)          # AttributeError here = header and library disagree
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()
+EXPORTS = ["mc_abi_version", "mc_last_error", "mc_table_compile", "mc_table_free", "mc_table_array", "mc_table_info",
+           "mc_ctx_hash", "mc_model_upload", "mc_model_destroy", "mc_model_check", "mc_sample", "mc_sample_injected",
+           "mc_score", "mc_rank_workspace_bytes", "mc_rank_build", "mc_rank_query"]
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise NativeError(rc, (lib.mc_last_error() or b"").decode("utf-8", "replace"))
+    return rc

@@ -1,0 +1,31 @@
+"""Backoff simulator: the reference's ``BackWordsMonteCarlo``
+(backwords_simulator.py:11-49)."""
+from typing import TextIO, Union
+
+from . import _native as nv
+from .backwords.backwords_trainer import backwords_counter
+from .lib4mc.ProbLib import expand_2d
+from .nwords_simulator import NWordsMonteCarlo
+
+
+class BackWordsMonteCarlo(NWordsMonteCarlo):
+    def __init__(self, training_set: Union[TextIO, None], splitter: str = '', start4word: int = 0, skip4word: int = 1,
+                 threshold: int = 10, start_chr: str = '\x00', end_chr: str = "\x03", max_gram: int = 256,
+                 max_iter: int = 10 ** 100):
+        super().__init__(None)
+        if training_set is None:
+            return
+        backwords, words = backwords_counter(training_set, splitter, start_chr, end_chr, start4word, skip4word,
+                                             threshold=threshold, max_gram=max_gram)
+        self._adopt(expand_2d(backwords), words, start_chr, end_chr, max_iter)
+
+    def _adopt(self, table, words, start_chr, end_chr, max_iter):
+        self.nwords = table
+        self.end_chr = end_chr
+        self.words = words
+        self.min_len = 4
+        self.default_start = start_chr
+        self.start_chr = start_chr
+        self.max_iter = max_iter
+        # the history starts as list(default_start): the characters of the start string
+        self._attach(nv.KIND_BACKOFF, order=0, start_units=tuple(start_chr), end_chr=end_chr, min_len=self.min_len)

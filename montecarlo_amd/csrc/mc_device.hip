@@ -1,0 +1,418 @@
+// Device residency + the sampling and scoring kernels (gfx950, wave64).
+//
+// Sampling (replaces MonteCarlo.sample -> sample1 -> pick_expand, reference
+// lib4mc/MonteCarloParent.py:33-46, nwords_simulator.py:92-116, lib4mc/ProbLib.py:31-43):
+// one lane per sampled string, persistent: a lane that finishes a string immediately
+// claims the next sample id of its workgroup from an LDS cursor, so lanes never wait for
+// the longest string of their wave.  Every step of a lane is one draw:
+//   state record (32 B) -> guide bucket (8 B) -> [0..few cum probes] -> payload (16 B).
+// The accumulation `prob += -log2 p` is done in fp64 in draw order, so ml2p is
+// bit-identical to the reference for the same uniforms.
+//
+// Scoring (replaces calc_ml2p for single-character alphabets, nwords_simulator.py:36-90,
+// backwords_simulator.py:28-49): one lane per test password walking the same automaton,
+// looking transitions up in the (row,symbol) hash and following parent links to back off.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "mc_internal.h"
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            mc_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return MC_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+namespace {
+
+struct alignas(16) StateRec {
+    double total;
+    uint32_t ent_off, len, guide_off, gbits, parent, ctx_len;
+};
+struct alignas(16) Payload {
+    double ml2p;
+    uint32_t next, sym;
+};
+struct alignas(16) Slot {
+    unsigned long long key;
+    uint32_t val, pad;
+};
+static_assert(sizeof(StateRec) == sizeof(mc_state_rec) && sizeof(StateRec) == 32, "state record layout");
+static_assert(sizeof(Payload) == sizeof(mc_payload) && sizeof(Payload) == 16, "payload layout");
+static_assert(sizeof(Slot) == sizeof(mc_slot) && sizeof(Slot) == 16, "slot layout");
+
+struct DevModel {
+    const StateRec *state;
+    const uint32_t *guide;
+    const double *cum;
+    const Payload *payload;
+    const Slot *trans;
+    const Slot *ctxhash;
+    const uint32_t *sym_chars;
+    unsigned long long *status;
+    unsigned long long trans_mask, ctx_mask;
+    uint32_t start_state, root, end_sym, min_len, max_len, flags, n_ctx, n_sym;
+};
+
+struct SampleArgs {
+    unsigned long long first_id, count, seed;
+    const double *uniforms;  // injected mode
+    double *out_ml2p;
+    uint32_t *out_len, *out_draws, *out_syms;
+    uint32_t max_draws, sym_stride;
+};
+
+constexpr uint32_t PH_M0 = 0xD2511F53u, PH_M1 = 0xCD9E8D57u, PH_W0 = 0x9E3779B9u, PH_W1 = 0xBB67AE85u;
+
+// Philox4x32-10; same bits as oracle/philox.py
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                               uint32_t k1, uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(PH_M0, c0), lo0 = PH_M0 * c0;
+        uint32_t hi1 = __umulhi(PH_M1, c2), lo1 = PH_M1 * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0;
+        c1 = lo1;
+        c2 = n2;
+        c3 = lo0;
+        k0 += PH_W0;
+        k1 += PH_W1;
+    }
+    o0 = c0;
+    o1 = c1;
+    o2 = c2;
+    o3 = c3;
+}
+
+template <bool INJECT, bool MULTICHAR>
+__global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
+    __shared__ unsigned int cursor;
+    __shared__ unsigned int blk_cnt[4];
+    const unsigned long long per = (a.count + gridDim.x - 1) / gridDim.x;
+    const unsigned long long b0 = min(a.count, (unsigned long long)blockIdx.x * per);
+    const unsigned long long b1 = min(a.count, b0 + per);
+    const unsigned int nblk = (unsigned int)(b1 - b0);
+    if (threadIdx.x == 0) cursor = 0;
+    if (threadIdx.x < 4) blk_cnt[threadIdx.x] = 0;
+    __syncthreads();
+
+    unsigned int c_draws = 0, c_probes = 0, c_restart = 0, c_fail = 0;
+    unsigned int local = atomicAdd(&cursor, 1u);
+    bool active = local < nblk;
+
+    uint32_t state = m.start_state, plen = 0, nsym = 0, draw = 0;
+    uint32_t w2 = 0, w3 = 0;
+    double acc = 0.0;
+    const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
+    const bool keep_len = (m.flags & MC_FLAG_KEEP_LEN_ON_RESTART) != 0;
+
+    while (active) {
+        const unsigned long long i = b0 + local;
+        // ---- uniform -------------------------------------------------------------------
+        double r;
+        unsigned long long m53 = 0;
+        if (INJECT) {
+            r = a.uniforms[i * a.max_draws + draw];
+        } else {
+            uint32_t wa, wb;
+            if ((draw & 1u) == 0) {
+                const unsigned long long sid = a.first_id + i;
+                philox4x32_10((uint32_t)sid, (uint32_t)(sid >> 32), draw >> 1, 0u, k0, k1, wa, wb, w2, w3);
+            } else {
+                wa = w2;
+                wb = w3;
+            }
+            m53 = ((unsigned long long)(wa >> 5) << 26) | (unsigned long long)(wb >> 6);
+            r = (double)m53 * 0x1.0p-53;
+        }
+        // ---- inverse CDF: same index as bisect_right(cum, total * r) ---------------------
+        const StateRec rec = m.state[state];
+        uint32_t k;
+        if (INJECT) {
+            const double kk = r * (double)(1u << rec.gbits);
+            const uint32_t kmax = (1u << rec.gbits) - 1u;
+            k = kk >= (double)kmax ? kmax : (kk > 0.0 ? (uint32_t)kk : 0u);
+        } else {
+            k = (uint32_t)(m53 >> (53u - rec.gbits));
+        }
+        const uint32_t *g = m.guide + rec.guide_off + k;
+        uint32_t lo = g[0], hi = g[1];
+        const double x = rec.total * r;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (m.cum[mid] > x) hi = mid; else lo = mid + 1;
+            ++c_probes;
+        }
+        const Payload p = m.payload[lo];
+        acc += p.ml2p;
+        ++draw;
+        ++c_draws;
+        // ---- sample1's control flow (nwords_simulator.py:100-115) ------------------------
+        bool done = false, ok = false, restart = false;
+        if (p.sym & 0x80000000u) {
+            if (plen >= m.min_len) done = ok = true; else restart = true;
+        } else {
+            const uint32_t s = p.sym;
+            if (a.out_syms && nsym < a.sym_stride) a.out_syms[i * a.sym_stride + nsym] = s;
+            ++nsym;
+            plen += MULTICHAR ? m.sym_chars[s] : 1u;
+            state = p.next;
+            if (plen >= m.max_len) restart = true;
+        }
+        if (restart) {
+            state = m.start_state;
+            acc = 0.0;
+            nsym = 0;
+            if (!keep_len) plen = 0;
+            ++c_restart;
+        }
+        if (!done && (draw >= a.max_draws || state == MC_NONE)) {
+            done = true;  // ok stays false: the reference would loop on / crash here
+            ++c_fail;
+        }
+        if (done) {
+            a.out_ml2p[i] = ok ? acc : __longlong_as_double(0x7FF8000000000000ll);
+            if (a.out_len) a.out_len[i] = nsym;
+            if (a.out_draws) a.out_draws[i] = draw;
+            local = atomicAdd(&cursor, 1u);
+            active = local < nblk;
+            state = m.start_state;
+            acc = 0.0;
+            plen = nsym = draw = 0;
+        }
+    }
+    atomicAdd(&blk_cnt[0], c_draws);
+    atomicAdd(&blk_cnt[1], c_probes);
+    atomicAdd(&blk_cnt[2], c_restart);
+    atomicAdd(&blk_cnt[3], c_fail);
+    __syncthreads();
+    if (threadIdx.x < 4 && blk_cnt[threadIdx.x])
+        atomicAdd(&m.status[MC_CNT_DRAWS + threadIdx.x], (unsigned long long)blk_cnt[threadIdx.x]);
+}
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void __launch_bounds__(256) k_score(DevModel m, const uint32_t *__restrict__ syms,
+                                               const unsigned long long *__restrict__ off, unsigned long long count,
+                                               double *__restrict__ out) {
+    unsigned int c_probe = 0, c_step = 0;
+    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < count;
+         t += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned long long a = off[t], b = off[t + 1];
+        uint32_t state = m.start_state;
+        double acc = 0.0;
+        bool ok = true;
+        for (unsigned long long j = a; j <= b; ++j) {
+            const uint32_t s = j < b ? syms[j] : m.end_sym;
+            if (s >= m.n_sym || state == MC_NONE) {
+                ok = false;
+                break;
+            }
+            uint32_t row = state, e = MC_NONE;
+            while (row != MC_NONE) {  // longest suffix row that lists s (backwords_simulator.py:31-38)
+                const unsigned long long key = ((unsigned long long)row << 32) | s;
+                unsigned long long q = mix64(key + 0x9E3779B97F4A7C15ull) & m.trans_mask;
+                for (;;) {
+                    const Slot sl = m.trans[q];
+                    ++c_probe;
+                    if (sl.key == key) {
+                        e = sl.val;
+                        break;
+                    }
+                    if (sl.key == ~0ull) break;
+                    q = (q + 1) & m.trans_mask;
+                }
+                if (e != MC_NONE) break;
+                row = m.state[row].parent;
+            }
+            if (e == MC_NONE) {
+                ok = false;
+                break;
+            }
+            const Payload p = m.payload[e];
+            acc += p.ml2p;
+            state = p.next;
+            ++c_step;
+        }
+        out[t] = (ok && acc < 1022.0) ? acc : 1022.0;
+    }
+    // one atomic per wave
+    for (int o = 32; o > 0; o >>= 1) {
+        c_probe += __shfl_down(c_probe, o);
+        c_step += __shfl_down(c_step, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&m.status[MC_CNT_SCORE_PROBES], (unsigned long long)c_probe);
+        atomicAdd(&m.status[MC_CNT_SCORE_STEPS], (unsigned long long)c_step);
+    }
+}
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace
+
+struct mc_model {
+    int device;
+    int n_cu;
+    void *arena;
+    size_t arena_bytes;
+    DevModel dev;
+    bool multichar;
+};
+
+extern "C" int mc_model_upload(const mc_table *t, int device, mc_model **out) {
+    if (!t || !out) {
+        mc_set_error("mc_model_upload: null argument");
+        return MC_ERR_ARG;
+    }
+    *out = nullptr;
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
+    HIP_TRY(hipSetDevice(device));
+    mc_model *m = new (std::nothrow) mc_model();
+    if (!m) return MC_ERR_NOMEM;
+    m->device = device;
+    m->multichar = t->multichar;
+    m->arena_bytes = mc_table_device_bytes(t);
+    hipError_t e = hipMalloc(&m->arena, m->arena_bytes);
+    if (e != hipSuccess) {
+        mc_set_error("hipMalloc(%zu) failed: %s", m->arena_bytes, hipGetErrorString(e));
+        delete m;
+        hipSetDevice(prev);
+        return MC_ERR_NOMEM;
+    }
+    HIP_TRY(hipDeviceGetAttribute(&m->n_cu, hipDeviceAttributeMultiprocessorCount, device));
+    char *p = (char *)m->arena;
+    auto put = [&](const void *src, size_t bytes) -> void * {
+        void *dst = p;
+        if (bytes) (void)hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+        p += align256(bytes);
+        return dst;
+    };
+    DevModel &d = m->dev;
+    d.state = (const StateRec *)put(t->state.data(), t->state.size() * sizeof(mc_state_rec));
+    d.guide = (const uint32_t *)put(t->guide.data(), t->guide.size() * sizeof(uint32_t));
+    d.cum = (const double *)put(t->cum.data(), t->cum.size() * sizeof(double));
+    d.payload = (const Payload *)put(t->payload.data(), t->payload.size() * sizeof(mc_payload));
+    d.trans = (const Slot *)put(t->trans.data(), t->trans.size() * sizeof(mc_slot));
+    d.ctxhash = (const Slot *)put(t->ctxhash.data(), t->ctxhash.size() * sizeof(mc_slot));
+    d.sym_chars = (const uint32_t *)put(t->sym_chars.data(), t->sym_chars.size() * sizeof(uint32_t));
+    d.status = (unsigned long long *)p;
+    HIP_TRY(hipMemset(d.status, 0, MC_STATUS_WORDS * sizeof(uint64_t)));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipGetLastError());
+    d.trans_mask = t->trans.size() - 1;
+    d.ctx_mask = t->ctxhash.size() - 1;
+    d.start_state = t->start_state;
+    d.root = t->root;
+    d.end_sym = t->end_sym;
+    d.min_len = t->min_len;
+    d.max_len = t->max_len;
+    d.flags = t->flags;
+    d.n_ctx = t->n_ctx;
+    d.n_sym = t->n_sym;
+    HIP_TRY(hipSetDevice(prev));
+    *out = m;
+    return MC_OK;
+}
+
+extern "C" void mc_model_destroy(mc_model *m) {
+    if (!m) return;
+    if (m->arena) (void)hipFree(m->arena);
+    delete m;
+}
+
+extern "C" int mc_model_check(mc_model *m, void *stream, uint64_t counters[8]) {
+    if (!m) {
+        mc_set_error("mc_model_check: null model");
+        return MC_ERR_ARG;
+    }
+    uint64_t host[MC_STATUS_WORDS];
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(host, m->dev.status, sizeof host, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemsetAsync(m->dev.status, 0, sizeof host, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (counters) std::memcpy(counters, host, sizeof host);
+    if (host[MC_CNT_FAILED]) {
+        mc_set_error("%llu sample(s) did not reach the end symbol within max_draws (or walked into a missing row); "
+                     "the reference would not terminate on this model",
+                     (unsigned long long)host[MC_CNT_FAILED]);
+        return MC_ERR_DIVERGED;
+    }
+    return MC_OK;
+}
+
+static int launch_sample(mc_model *m, bool inject, const SampleArgs &a, hipStream_t s) {
+    if (a.count == 0) return MC_OK;
+    if (m->dev.start_state == MC_NONE) {
+        mc_set_error("the start context has no row (the reference exits in pick_expand, ProbLib.py:32-36)");
+        return MC_ERR_TABLE;
+    }
+    // 8 workgroups of 256 lanes per CU keep every SIMD at 8 waves; each workgroup's share must fit u32
+    unsigned long long want = (a.count + 63) / 64;
+    unsigned long long cap = (unsigned long long)m->n_cu * 8;
+    unsigned long long grid = want < cap ? want : cap;
+    while ((a.count + grid - 1) / grid > 0x7FFFFFFFull) grid *= 2;
+    dim3 g((unsigned)grid), b(256);
+    if (inject) {
+        if (m->multichar) hipLaunchKernelGGL((k_sample<true, true>), g, b, 0, s, m->dev, a);
+        else hipLaunchKernelGGL((k_sample<true, false>), g, b, 0, s, m->dev, a);
+    } else {
+        if (m->multichar) hipLaunchKernelGGL((k_sample<false, true>), g, b, 0, s, m->dev, a);
+        else hipLaunchKernelGGL((k_sample<false, false>), g, b, 0, s, m->dev, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return MC_OK;
+}
+
+extern "C" int mc_sample(mc_model *m, uint64_t first_id, uint64_t count, uint64_t seed, uint32_t max_draws,
+                         double *out_ml2p, uint32_t *out_len, uint32_t *out_draws, uint32_t *out_syms,
+                         uint32_t sym_stride, void *stream) {
+    if (!m || (count && !out_ml2p) || max_draws == 0 || (out_syms && sym_stride == 0)) {
+        mc_set_error("mc_sample: bad argument");
+        return MC_ERR_ARG;
+    }
+    SampleArgs a{first_id, count, seed, nullptr, out_ml2p, out_len, out_draws, out_syms, max_draws, sym_stride};
+    return launch_sample(m, false, a, (hipStream_t)stream);
+}
+
+extern "C" int mc_sample_injected(mc_model *m, uint64_t count, const double *uniforms, uint32_t draws_per_sample,
+                                  double *out_ml2p, uint32_t *out_len, uint32_t *out_draws, uint32_t *out_syms,
+                                  uint32_t sym_stride, void *stream) {
+    if (!m || (count && (!out_ml2p || !uniforms)) || draws_per_sample == 0 || (out_syms && sym_stride == 0)) {
+        mc_set_error("mc_sample_injected: bad argument");
+        return MC_ERR_ARG;
+    }
+    SampleArgs a{0, count, 0, uniforms, out_ml2p, out_len, out_draws, out_syms, draws_per_sample, sym_stride};
+    return launch_sample(m, true, a, (hipStream_t)stream);
+}
+
+extern "C" int mc_score(mc_model *m, const uint32_t *syms, const uint64_t *off, uint64_t count, double *out_ml2p,
+                        void *stream) {
+    if (!m || (count && (!off || !out_ml2p))) {
+        mc_set_error("mc_score: bad argument");
+        return MC_ERR_ARG;
+    }
+    if (count == 0) return MC_OK;
+    if (m->multichar) {
+        mc_set_error("mc_score walks single-character alphabets only; this model has multi-character symbols");
+        return MC_ERR_ARG;
+    }
+    unsigned long long want = (count + 255) / 256, cap = (unsigned long long)m->n_cu * 8;
+    dim3 g((unsigned)(want < cap ? want : cap)), b(256);
+    hipLaunchKernelGGL(k_score, g, b, 0, (hipStream_t)stream, m->dev, syms, (const unsigned long long *)off,
+                       (unsigned long long)count, out_ml2p);
+    HIP_TRY(hipGetLastError());
+    return MC_OK;
+}

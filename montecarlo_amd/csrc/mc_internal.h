@@ -1,0 +1,36 @@
+// Internal declarations shared by the table compiler (host) and the HIP side.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "../../include/mi355mc.h"
+
+#define MC_STATUS_WORDS 8
+// status/counter words kept in device memory per model
+enum {
+    MC_CNT_DRAWS = 0,      // uniforms consumed
+    MC_CNT_PROBES = 1,     // cum[] comparisons inside guide buckets
+    MC_CNT_RESTARTS = 2,   // samples restarted (too short / too long)
+    MC_CNT_FAILED = 3,     // samples that hit max_draws or a missing row
+    MC_CNT_SCORE_PROBES = 4,  // transition-hash slots read while scoring
+    MC_CNT_SCORE_STEPS = 5    // symbols consumed while scoring
+};
+
+struct mc_table {
+    uint32_t kind, order, n_ctx, n_sym;
+    uint64_t n_ent;
+    uint32_t end_sym, min_len, max_len, flags;
+    uint32_t start_state, root, max_row;
+    bool multichar;
+    std::vector<mc_state_rec> state;
+    std::vector<uint32_t> guide;
+    std::vector<double> cum;
+    std::vector<mc_payload> payload;
+    std::vector<mc_slot> trans;
+    std::vector<mc_slot> ctxhash;
+    std::vector<uint32_t> sym_chars;
+};
+
+void mc_set_error(const char *fmt, ...);
+uint64_t mc_trans_hash(uint64_t key);
+size_t mc_table_device_bytes(const mc_table *t);

@@ -1,0 +1,436 @@
+// Rank estimation kernels (gfx950): replaces MonteCarloLib.__init__ / ml2p2rank,
+// reference lib4mc/MonteCarloLib.py:10-32:
+//     keys.sort(); positions = cumsum(2 ** (keys - log2 n)); bisect_right(keys, x)
+//
+//   sort      LSD radix sort of the fp64 keys as u64 (keys are >= +0.0, so IEEE bit order is
+//             numeric order; NaN = failed sample sorts last), 8-bit digits.  One upfront
+//             kernel builds all 8 digit histograms; passes whose digit is constant over the
+//             whole input (the sign/exponent bytes, typically) are skipped and the ping-pong
+//             is planned so the last pass lands in keys_sorted.  Each pass: per-workgroup
+//             digit counts -> exclusive scan (digit-major) -> stable scatter, the scatter
+//             staged through LDS so global writes are digit-contiguous runs.
+//   scan      positions = inclusive prefix sum of exp2(key - log2 n_global), fp64,
+//             reduce-then-scan over per-workgroup chunks.
+//   query     one lane per test password: upper_bound over the sorted keys.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "mc_internal.h"
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            mc_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return MC_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+namespace {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_ITEMS = 16;
+constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 4096 keys per tile
+constexpr int SORT_MAX_BLOCKS = 2048;
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+constexpr int SCAN_MAX_BLOCKS = 2048;
+
+// workspace layout (u32 words unless noted)
+struct Plan {
+    u32 skip[8];   // pass is a no-op
+    u32 src[8];    // 0 = keys_in, 1 = keys_sorted (A), 2 = temp (B)
+    u32 dst[8];
+    u32 n_active;
+};
+
+struct SortWs {
+    u64 *temp;        // [n] second key buffer
+    u32 *hist;        // [8][256]
+    u32 *counts;      // [256][nblocks] digit-major
+    Plan *plan;
+    double *partials; // [scan blocks]
+};
+
+__device__ __forceinline__ u32 digit_of(u64 k, int pass) { return (u32)(k >> (8 * pass)) & 255u; }
+
+// ---- all 8 digit histograms in one read ------------------------------------------------------
+__global__ void __launch_bounds__(256) k_hist_all(const u64 *__restrict__ keys, u64 n, u32 *__restrict__ hist) {
+    __shared__ u32 h[8 * 256];
+    for (int i = threadIdx.x; i < 8 * 256; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 k = keys[i];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) atomicAdd(&h[p * 256 + digit_of(k, p)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 8 * 256; i += blockDim.x)
+        if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+// one workgroup: which passes do anything, and which buffer each reads/writes
+__global__ void k_plan(const u32 *__restrict__ hist, u64 n, Plan *plan) {
+    __shared__ u32 trivial[8];
+    if (threadIdx.x < 8) trivial[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 8 * 256; i += blockDim.x)
+        if ((u64)hist[i] == n) trivial[i >> 8] = 1;  // benign race: every writer stores 1
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 active = 0;
+        for (int p = 0; p < 8; ++p) active += trivial[p] ? 0 : 1;
+        // destinations alternate and the LAST active pass must write A (keys_sorted)
+        u32 cur_src = 0, k = 0;
+        for (int p = 0; p < 8; ++p) {
+            plan->skip[p] = trivial[p];
+            plan->src[p] = plan->dst[p] = 0;
+            if (trivial[p]) continue;
+            u32 remaining_after = active - k - 1;
+            u32 d = (remaining_after % 2 == 0) ? 1 : 2;
+            plan->src[p] = cur_src;
+            plan->dst[p] = d;
+            cur_src = d;
+            ++k;
+        }
+        plan->n_active = active;
+    }
+}
+
+__device__ __forceinline__ const u64 *pick_src(u32 id, const u64 *in, const u64 *a, const u64 *b) {
+    return id == 0 ? in : (id == 1 ? a : b);
+}
+
+// nothing to sort by (all passes trivial): keys_sorted = keys_in
+__global__ void __launch_bounds__(256) k_copy_if_unsorted(const Plan *__restrict__ plan, const u64 *__restrict__ in,
+                                                          u64 *__restrict__ out, u64 n) {
+    if (plan->n_active != 0) return;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) out[i] = in[i];
+}
+
+// ---- per pass: digit counts of each workgroup's chunk ----------------------------------------
+__global__ void __launch_bounds__(SORT_THREADS) k_count(const Plan *__restrict__ plan, int pass, const u64 *in,
+                                                         const u64 *a, const u64 *b, u64 n, u64 chunk,
+                                                         u32 *__restrict__ counts) {
+    if (plan->skip[pass]) return;
+    const u64 *src = pick_src(plan->src[pass], in, a, b);
+    __shared__ u32 h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
+    for (u64 i = lo + threadIdx.x; i < hi; i += SORT_THREADS) atomicAdd(&h[digit_of(src[i], pass)], 1u);
+    __syncthreads();
+    counts[(u64)threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
+}
+
+// exclusive scan of counts[256*nblocks] in place, one workgroup of 1024 lanes
+__global__ void __launch_bounds__(1024) k_scan_counts(const Plan *__restrict__ plan, int pass, u32 *counts, u32 len) {
+    if (plan->skip[pass]) return;
+    __shared__ u32 wave_tot[16];
+    __shared__ u32 carry_s;
+    const u32 per = (len + 1023) / 1024;
+    const u32 lo = min(len, threadIdx.x * per), hi = min(len, lo + per);
+    u32 sum = 0;
+    for (u32 i = lo; i < hi; ++i) sum += counts[i];
+    // block-wide exclusive scan of `sum`
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    u32 inc = sum;
+    for (int o = 1; o < 64; o <<= 1) {
+        u32 v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+    }
+    if (lane == 63) wave_tot[wid] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 c = 0;
+        for (int w = 0; w < 16; ++w) {
+            u32 v = wave_tot[w];
+            wave_tot[w] = c;
+            c += v;
+        }
+        carry_s = c;
+    }
+    __syncthreads();
+    u32 run = wave_tot[wid] + inc - sum;
+    for (u32 i = lo; i < hi; ++i) {
+        u32 v = counts[i];
+        counts[i] = run;
+        run += v;
+    }
+}
+
+// ---- per pass: stable scatter -----------------------------------------------------------------
+__global__ void __launch_bounds__(SORT_THREADS) k_scatter(const Plan *__restrict__ plan, int pass, const u64 *in,
+                                                           u64 *a, u64 *b, u64 n, u64 chunk,
+                                                           const u32 *__restrict__ counts) {
+    if (plan->skip[pass]) return;
+    const u64 *src = pick_src(plan->src[pass], in, a, b);
+    u64 *dst = plan->dst[pass] == 1 ? a : b;
+    __shared__ u64 stage[SORT_TILE];
+    __shared__ u32 wcnt[4][256];   // per-wave digit counts of the tile, then exclusive prefix over waves
+    __shared__ u32 base[256];      // running global write offset of each digit for this workgroup
+    __shared__ u32 tile_off[256];  // exclusive scan of the tile's digit counts
+    __shared__ u32 wave_sum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    base[tid] = counts[(u64)tid * gridDim.x + blockIdx.x];
+    const u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
+    for (u64 t0 = lo; t0 < hi; t0 += SORT_TILE) {
+        const u32 tile_n = (u32)min((u64)SORT_TILE, hi - t0);
+        for (int w = 0; w < 4; ++w) wcnt[w][tid] = 0;
+        __syncthreads();
+        // each wave owns 1024 consecutive keys of the tile: order = (wave, round, lane)
+        u64 key[SORT_ITEMS];
+        u32 rank[SORT_ITEMS];
+#pragma unroll
+        for (int r = 0; r < SORT_ITEMS; ++r) {
+            const u32 j = wid * (64 * SORT_ITEMS) + r * 64 + lane;
+            const bool valid = j < tile_n;
+            key[r] = valid ? src[t0 + j] : ~0ull;
+            const u32 d = digit_of(key[r], pass);
+            // lanes of this wave holding the same digit (invalid lanes match nobody)
+            u64 peers = __ballot(valid);
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const u64 vote = __ballot((d >> bit) & 1u);
+                peers &= ((d >> bit) & 1u) ? vote : ~vote;
+            }
+            const u32 before = __popcll(peers & ((1ull << lane) - 1ull));
+            const u32 cnt = __popcll(peers);
+            const int leader = __ffsll((long long)peers) - 1;
+            u32 old = 0;
+            if (valid && lane == leader) old = atomicAdd(&wcnt[wid][d], cnt);
+            old = __shfl(old, leader < 0 ? 0 : leader);
+            rank[r] = old + before;
+        }
+        __syncthreads();
+        // digit `tid`: exclusive prefix over the 4 waves, tile total
+        u32 c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid], c3 = wcnt[3][tid];
+        const u32 tot = c0 + c1 + c2 + c3;
+        wcnt[0][tid] = 0;
+        wcnt[1][tid] = c0;
+        wcnt[2][tid] = c0 + c1;
+        wcnt[3][tid] = c0 + c1 + c2;
+        // exclusive scan of tot over the 256 digits
+        u32 inc = tot;
+        for (int o = 1; o < 64; o <<= 1) {
+            u32 v = __shfl_up(inc, o);
+            if (lane >= o) inc += v;
+        }
+        if (lane == 63) wave_sum[wid] = inc;
+        __syncthreads();
+        u32 woff = 0;
+        for (int w = 0; w < wid; ++w) woff += wave_sum[w];
+        tile_off[tid] = woff + inc - tot;
+        __syncthreads();
+        // stage keys in LDS in digit order
+#pragma unroll
+        for (int r = 0; r < SORT_ITEMS; ++r) {
+            const u32 j = wid * (64 * SORT_ITEMS) + r * 64 + lane;
+            if (j < tile_n) {
+                const u32 d = digit_of(key[r], pass);
+                stage[tile_off[d] + wcnt[wid][d] + rank[r]] = key[r];
+            }
+        }
+        __syncthreads();
+        // digit-contiguous runs out to global
+        for (u32 j = tid; j < tile_n; j += SORT_THREADS) {
+            const u64 k = stage[j];
+            const u32 d = digit_of(k, pass);
+            dst[(u64)base[d] + (j - tile_off[d])] = k;
+        }
+        __syncthreads();
+        base[tid] += tot;
+        // (the next iteration's first __syncthreads orders this against its readers)
+    }
+}
+
+// ---- positions: prefix sum of 2^(key - log2 n_global) ------------------------------------------
+__device__ __forceinline__ double block_inclusive_scan(double v, double *wave_tot, double &block_total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double inc = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        double u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
+    }
+    __syncthreads();  // protect wave_tot from the previous use
+    if (lane == 63) wave_tot[wid] = inc;
+    __syncthreads();
+    double off = 0.0, tot = 0.0;
+    for (int w = 0; w < SCAN_THREADS / 64; ++w) {
+        const double t = wave_tot[w];
+        if (w < wid) off += t;
+        tot += t;
+    }
+    block_total = tot;
+    return off + inc;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) k_weight_sums(const double *__restrict__ keys, u64 n, u64 chunk,
+                                                               double logn, double *__restrict__ partials) {
+    __shared__ double wave_tot[SCAN_THREADS / 64];
+    const u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
+    double s = 0.0;
+    for (u64 i = lo + threadIdx.x; i < hi; i += SCAN_THREADS) s += exp2(keys[i] - logn);
+    double tot;
+    (void)block_inclusive_scan(s, wave_tot, tot);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_partials(double *partials, u32 nb) {
+    // nb <= SCAN_MAX_BLOCKS: a single workgroup, sequential per lane then a block scan
+    __shared__ double wave_tot[SCAN_THREADS / 64];
+    const u32 per = (nb + SCAN_THREADS - 1) / SCAN_THREADS;
+    const u32 lo = min(nb, threadIdx.x * per), hi = min(nb, lo + per);
+    double s = 0.0;
+    for (u32 i = lo; i < hi; ++i) s += partials[i];
+    double tot;
+    double run = block_inclusive_scan(s, wave_tot, tot) - s;
+    for (u32 i = lo; i < hi; ++i) {
+        const double v = partials[i];
+        partials[i] = run;  // exclusive
+        run += v;
+    }
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) k_positions(const double *__restrict__ keys, u64 n, u64 chunk,
+                                                             double logn, const double *__restrict__ partials,
+                                                             double *__restrict__ pos) {
+    __shared__ double wave_tot[SCAN_THREADS / 64];
+    const u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
+    double carry = partials[blockIdx.x];
+    for (u64 t0 = lo; t0 < hi; t0 += SCAN_TILE) {
+        // lane owns SCAN_ITEMS consecutive keys
+        const u64 i0 = t0 + (u64)threadIdx.x * SCAN_ITEMS;
+        double w[SCAN_ITEMS];
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; ++j) {
+            w[j] = (i0 + j < hi) ? exp2(keys[i0 + j] - logn) : 0.0;
+            s += w[j];
+            w[j] = s;  // inclusive within the lane
+        }
+        double tot;
+        const double excl = block_inclusive_scan(s, wave_tot, tot) - s;
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; ++j)
+            if (i0 + j < hi) pos[i0 + j] = carry + (excl + w[j]);
+        carry += tot;
+    }
+}
+
+// ---- ml2p2rank for a batch ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_query(const double *__restrict__ keys, const double *__restrict__ pos, u64 n,
+                                               const double *__restrict__ x, u64 t, double *__restrict__ out_pos,
+                                               u64 *__restrict__ out_cnt) {
+    for (u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x; q < t; q += (u64)gridDim.x * blockDim.x) {
+        const double v = x[q];
+        u64 lo = 0, hi = n;  // first index with keys[i] > v  (bisect_right)
+        while (lo < hi) {
+            const u64 mid = (lo + hi) >> 1;
+            if (keys[mid] > v) hi = mid; else lo = mid + 1;
+        }
+        if (out_cnt) out_cnt[q] = lo;
+        out_pos[q] = lo ? pos[lo - 1] : 0.0;
+    }
+}
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+u32 sort_blocks(u64 n) {
+    u64 tiles = (n + SORT_TILE - 1) / SORT_TILE;
+    return (u32)(tiles < (u64)SORT_MAX_BLOCKS ? (tiles ? tiles : 1) : SORT_MAX_BLOCKS);
+}
+u32 scan_blocks(u64 n) {
+    u64 tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    return (u32)(tiles < (u64)SCAN_MAX_BLOCKS ? (tiles ? tiles : 1) : SCAN_MAX_BLOCKS);
+}
+
+}  // namespace
+
+extern "C" size_t mc_rank_workspace_bytes(uint64_t n) {
+    return align256(n * sizeof(u64)) + align256(8 * 256 * sizeof(u32)) +
+           align256((size_t)256 * SORT_MAX_BLOCKS * sizeof(u32)) + align256(sizeof(Plan)) +
+           align256(SCAN_MAX_BLOCKS * sizeof(double));
+}
+
+extern "C" int mc_rank_build(const double *keys_in, uint64_t n, uint64_t n_global, double *keys_sorted,
+                             double *positions, void *workspace, size_t workspace_bytes, void *stream) {
+    if (n == 0) return MC_OK;
+    if (!keys_in || !keys_sorted || !positions || !workspace || n_global < n) {
+        mc_set_error("mc_rank_build: bad argument");
+        return MC_ERR_ARG;
+    }
+    if (n >= 0xFFFFFFFFull) {
+        mc_set_error("mc_rank_build: n must be below 2^32 per GPU (got %llu)", (unsigned long long)n);
+        return MC_ERR_ARG;
+    }
+    if (workspace_bytes < mc_rank_workspace_bytes(n)) {
+        mc_set_error("mc_rank_build: workspace of %zu bytes, need %zu", workspace_bytes, mc_rank_workspace_bytes(n));
+        return MC_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    char *p = (char *)workspace;
+    SortWs ws;
+    ws.temp = (u64 *)p;
+    p += align256(n * sizeof(u64));
+    ws.hist = (u32 *)p;
+    p += align256(8 * 256 * sizeof(u32));
+    ws.counts = (u32 *)p;
+    p += align256((size_t)256 * SORT_MAX_BLOCKS * sizeof(u32));
+    ws.plan = (Plan *)p;
+    p += align256(sizeof(Plan));
+    ws.partials = (double *)p;
+
+    const u64 *in = (const u64 *)keys_in;
+    u64 *A = (u64 *)keys_sorted, *B = ws.temp;
+    HIP_TRY(hipMemsetAsync(ws.hist, 0, 8 * 256 * sizeof(u32), s));
+    {
+        u64 want = (n + 255) / 256;
+        u32 g = (u32)(want < 2048 ? want : 2048);
+        hipLaunchKernelGGL(k_hist_all, dim3(g), dim3(256), 0, s, in, (u64)n, ws.hist);
+        hipLaunchKernelGGL(k_plan, dim3(1), dim3(256), 0, s, ws.hist, (u64)n, ws.plan);
+        hipLaunchKernelGGL(k_copy_if_unsorted, dim3(g), dim3(256), 0, s, ws.plan, in, A, (u64)n);
+    }
+    const u32 nb = sort_blocks(n);
+    const u64 tiles = (n + SORT_TILE - 1) / SORT_TILE;
+    const u64 chunk = ((tiles + nb - 1) / nb) * SORT_TILE;  // whole tiles per workgroup
+    for (int pass = 0; pass < 8; ++pass) {
+        hipLaunchKernelGGL(k_count, dim3(nb), dim3(SORT_THREADS), 0, s, ws.plan, pass, in, (const u64 *)A,
+                           (const u64 *)B, (u64)n, chunk, ws.counts);
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, ws.plan, pass, ws.counts, 256u * nb);
+        hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(SORT_THREADS), 0, s, ws.plan, pass, in, A, B, (u64)n, chunk,
+                           ws.counts);
+    }
+    // positions
+    const double logn = std::log2((double)n_global);
+    const u32 sb = scan_blocks(n);
+    const u64 stiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    const u64 schunk = ((stiles + sb - 1) / sb) * SCAN_TILE;
+    hipLaunchKernelGGL(k_weight_sums, dim3(sb), dim3(SCAN_THREADS), 0, s, (const double *)keys_sorted, (u64)n, schunk,
+                       logn, ws.partials);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(SCAN_THREADS), 0, s, ws.partials, sb);
+    hipLaunchKernelGGL(k_positions, dim3(sb), dim3(SCAN_THREADS), 0, s, (const double *)keys_sorted, (u64)n, schunk,
+                       logn, (const double *)ws.partials, positions);
+    HIP_TRY(hipGetLastError());
+    return MC_OK;
+}
+
+extern "C" int mc_rank_query(const double *keys_sorted, const double *positions, uint64_t n, const double *x,
+                             uint64_t t, double *out_pos, uint64_t *out_cnt, void *stream) {
+    if (t == 0) return MC_OK;
+    if (!x || !out_pos || (n && (!keys_sorted || !positions))) {
+        mc_set_error("mc_rank_query: bad argument");
+        return MC_ERR_ARG;
+    }
+    u64 want = (t + 255) / 256;
+    u32 g = (u32)(want < 4096 ? want : 4096);
+    hipLaunchKernelGGL(k_query, dim3(g), dim3(256), 0, (hipStream_t)stream, keys_sorted, positions, (u64)n, x, (u64)t,
+                       out_pos, (u64 *)out_cnt);
+    HIP_TRY(hipGetLastError());
+    return MC_OK;
+}

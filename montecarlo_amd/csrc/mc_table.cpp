@@ -1,0 +1,358 @@
+// Table compiler: dict-of-dict model (flattened by the caller) -> walk automaton.
+//
+// The reference recomputes, for every emitted symbol, which table row applies
+// (`_get_prefix`: nwords_simulator.py:30-34, backwords_simulator.py:28-41 -- tuple
+// builds + dict probes over every suffix of the history) and bisects the row's
+// cumulative sums (lib4mc/ProbLib.py:40-41).  On the GPU both are replaced by data:
+//   * next[e]   : the row that applies after taking entry e (one u32 per entry);
+//   * parent[r] : the next shorter row that is a suffix of row r's context (backoff);
+//   * guide     : per row, 2^gbits buckets over the uniform; bucket k stores the first
+//                 and last entry the draw can land on, so the exact fp64 comparison
+//                 `cum[i] > total*r` is only evaluated inside that (usually one-entry)
+//                 range.  The result is the same index bisect_right returns.
+//   * trans     : open-addressed (row,symbol) -> entry hash for scoring;
+//   * ctxhash   : open-addressed 64-bit context hash -> row index (by-context lookups).
+// Host-only code: no HIP here, so it is testable in a container without a GPU.
+#include "mc_internal.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+static thread_local std::string g_err;
+
+void mc_set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+extern "C" const char *mc_last_error(void) { return g_err.c_str(); }
+extern "C" int mc_abi_version(void) { return MC_ABI_VERSION; }
+
+static inline uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+extern "C" uint64_t mc_ctx_hash(const uint32_t *units, uint32_t n) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t)n << 32);
+    for (uint32_t i = 0; i < n; ++i) h = mix64(h ^ ((uint64_t)units[i] + 0x632BE59BD9B4E019ull));
+    if (h == ~0ull) h = ~0ull - 1;  // ~0 marks an empty slot
+    return h;
+}
+
+uint64_t mc_trans_hash(uint64_t key) { return mix64(key + 0x9E3779B97F4A7C15ull); }
+
+namespace {
+
+uint64_t pow2ceil(uint64_t v) {
+    uint64_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+struct CtxIndex {
+    const mc_model_desc *d;
+    std::vector<mc_slot> slots;
+    uint64_t mask;
+
+    bool same(uint32_t row, const uint32_t *u, uint32_t n) const {
+        uint32_t a = d->ctx_off[row], b = d->ctx_off[row + 1];
+        return b - a == n && (n == 0 || std::memcmp(d->ctx_units + a, u, n * sizeof(uint32_t)) == 0);
+    }
+    // returns MC_NONE when absent
+    uint32_t find(const uint32_t *u, uint32_t n) const {
+        uint64_t h = mc_ctx_hash(u, n);
+        for (uint64_t i = h & mask;; i = (i + 1) & mask) {
+            const mc_slot &s = slots[i];
+            if (s.key == ~0ull) return MC_NONE;
+            if (s.key == h && same(s.val, u, n)) return s.val;
+        }
+    }
+    int build(const mc_model_desc *desc) {
+        d = desc;
+        uint64_t cap = pow2ceil(std::max<uint64_t>(16, 2ull * desc->n_ctx));
+        mask = cap - 1;
+        slots.assign(cap, mc_slot{~0ull, 0, 0});
+        for (uint32_t r = 0; r < desc->n_ctx; ++r) {
+            uint32_t a = desc->ctx_off[r], n = desc->ctx_off[r + 1] - a;
+            uint64_t h = mc_ctx_hash(desc->ctx_units + a, n);
+            for (uint64_t i = h & mask;; i = (i + 1) & mask) {
+                mc_slot &s = slots[i];
+                if (s.key == ~0ull) {
+                    s = mc_slot{h, r, n};
+                    break;
+                }
+                if (s.key == h) {
+                    if (same(s.val, desc->ctx_units + a, n)) {
+                        mc_set_error("context rows %u and %u are the same context", s.val, r);
+                    } else {
+                        mc_set_error("64-bit context hash collision between rows %u and %u", s.val, r);
+                    }
+                    return MC_ERR_TABLE;
+                }
+            }
+        }
+        return MC_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" int mc_table_compile(const mc_model_desc *d, mc_table **out) {
+    if (!d || !out) {
+        mc_set_error("mc_table_compile: null argument");
+        return MC_ERR_ARG;
+    }
+    *out = nullptr;
+    if (d->kind != MC_KIND_NGRAM && d->kind != MC_KIND_BACKOFF && d->kind != MC_KIND_V2) {
+        mc_set_error("unknown model kind %u", d->kind);
+        return MC_ERR_ARG;
+    }
+    if (!d->ctx_off || !d->row_off || !d->ent_sym || !d->ent_cum || !d->ent_ml2p || (d->n_start && !d->start_units) ||
+        (d->ctx_off[d->n_ctx] && !d->ctx_units)) {
+        mc_set_error("mc_table_compile: null array in descriptor");
+        return MC_ERR_ARG;
+    }
+    if (d->n_ctx == 0 || d->n_ctx >= MC_NONE || d->n_ent == 0 || d->n_ent >= 0x7FFFFFFFull || d->n_sym == 0 ||
+        d->n_sym >= 0x7FFFFFFFu || d->end_sym >= d->n_sym) {
+        mc_set_error("mc_table_compile: sizes out of range (n_ctx=%u n_ent=%llu n_sym=%u end_sym=%u)", d->n_ctx,
+                     (unsigned long long)d->n_ent, d->n_sym, d->end_sym);
+        return MC_ERR_ARG;
+    }
+    if (d->kind != MC_KIND_BACKOFF && d->order == 0) {
+        mc_set_error("fixed-order models need order >= 1 (n >= 2)");
+        return MC_ERR_ARG;
+    }
+    if (d->row_off[0] != 0 || d->row_off[d->n_ctx] != d->n_ent || d->ctx_off[0] != 0) {
+        mc_set_error("row_off/ctx_off must start at 0 and row_off must end at n_ent");
+        return MC_ERR_ARG;
+    }
+    for (uint32_t r = 0; r < d->n_ctx; ++r) {
+        if (d->row_off[r + 1] <= d->row_off[r]) {
+            mc_set_error("row %u is empty (expand_2d drops empty rows, ProbLib.py:14-15)", r);
+            return MC_ERR_TABLE;
+        }
+        if (d->ctx_off[r + 1] < d->ctx_off[r]) {
+            mc_set_error("ctx_off not monotone at row %u", r);
+            return MC_ERR_ARG;
+        }
+    }
+    for (uint64_t e = 0; e < d->n_ent; ++e)
+        if (d->ent_sym[e] >= d->n_sym) {
+            mc_set_error("entry %llu has symbol id %u >= n_sym", (unsigned long long)e, d->ent_sym[e]);
+            return MC_ERR_ARG;
+        }
+
+    CtxIndex idx;
+    int rc = idx.build(d);
+    if (rc != MC_OK) return rc;
+
+    mc_table *t = new mc_table();
+    t->kind = d->kind;
+    t->order = d->order;
+    t->n_ctx = d->n_ctx;
+    t->n_sym = d->n_sym;
+    t->n_ent = d->n_ent;
+    t->end_sym = d->end_sym;
+    t->min_len = d->min_len;
+    t->max_len = d->max_len;
+    t->flags = d->flags;
+    t->ctxhash = idx.slots;
+    t->sym_chars.assign(d->n_sym, 1);
+    t->multichar = false;
+    if (d->sym_chars)
+        for (uint32_t s = 0; s < d->n_sym; ++s) {
+            t->sym_chars[s] = d->sym_chars[s];
+            if (d->sym_chars[s] != 1 && s != d->end_sym) t->multichar = true;
+        }
+
+    const bool backoff = d->kind == MC_KIND_BACKOFF;
+    // the row that applies to a history `u[0..n)`, by the model's own context rule
+    auto state_of = [&](const uint32_t *u, uint32_t n) -> uint32_t {
+        if (backoff) {
+            for (uint32_t i = 0; i <= n; ++i) {  // longest suffix first, the empty context last
+                uint32_t r = idx.find(u + i, n - i);
+                if (r != MC_NONE) return r;
+            }
+            return MC_NONE;
+        }
+        uint32_t keep = std::min(n, d->order);
+        return idx.find(u + (n - keep), keep);
+    };
+
+    t->root = idx.find(nullptr, 0);
+    t->start_state = state_of(d->start_units, d->n_start);
+
+    if (backoff) {
+        // Exactness of the automaton: state(h+s) must equal the longest suffix of state(h)+s that
+        // is a row.  That holds iff the rows are prefix-closed (w+s a row => w a row), which every
+        // trainer of the reference guarantees (count[w][s] >= total(w+s) >= threshold).
+        for (uint32_t r = 0; r < d->n_ctx; ++r) {
+            uint32_t a = d->ctx_off[r], n = d->ctx_off[r + 1] - a;
+            if (n == 0) continue;
+            if (idx.find(d->ctx_units + a, n - 1) == MC_NONE) {
+                mc_set_error("backoff rows are not prefix-closed: row %u (context length %u) has no row for its "
+                             "context minus the last symbol; the compiled walk would not be exact",
+                             r, n);
+                delete t;
+                return MC_ERR_TABLE;
+            }
+        }
+    }
+
+    // ---- state records, guide tables, payloads -------------------------------------------
+    uint32_t gf = d->guide_factor ? d->guide_factor : 2;
+    t->state.resize(d->n_ctx);
+    t->cum.assign(d->ent_cum, d->ent_cum + d->n_ent);
+    t->payload.resize(d->n_ent);
+    t->max_row = 0;
+    std::vector<uint32_t> seq;
+    for (uint32_t r = 0; r < d->n_ctx; ++r) {
+        const uint64_t e0 = d->row_off[r], e1 = d->row_off[r + 1];
+        const uint32_t L = (uint32_t)(e1 - e0);
+        const uint32_t ca = d->ctx_off[r], cn = d->ctx_off[r + 1] - ca;
+        const double *cum = d->ent_cum + e0;
+        mc_state_rec &st = t->state[r];
+        st.total = cum[L - 1];
+        st.ent_off = (uint32_t)e0;
+        st.len = L;
+        st.ctx_len = cn;
+        st.parent = MC_NONE;
+        t->max_row = std::max(t->max_row, L);
+        for (uint32_t i = 1; i < L; ++i)
+            if (!(cum[i] >= cum[i - 1])) {
+                mc_set_error("row %u: cumulative sums decrease at entry %u", r, i);
+                delete t;
+                return MC_ERR_TABLE;
+            }
+        if (!(st.total > 0.0)) {
+            mc_set_error("row %u: total probability mass is not positive", r);
+            delete t;
+            return MC_ERR_TABLE;
+        }
+        if (backoff && cn > 0) {
+            for (uint32_t i = 1; i <= cn; ++i) {
+                uint32_t p = idx.find(d->ctx_units + ca + i, cn - i);
+                if (p != MC_NONE) {
+                    st.parent = p;
+                    break;
+                }
+            }
+        }
+        // guide: K = 2^gbits buckets over r in [0,1); bucket k can only land on entries
+        // [upper_bound(cum, total*k/K), upper_bound(cum, total*(k+1)/K)] (clamped to L-1).
+        uint32_t gbits = 0;
+        if (L > 1) {
+            uint64_t K = pow2ceil((uint64_t)gf * L);
+            while ((1ull << gbits) < K) ++gbits;
+            if (gbits > 16) gbits = 16;
+        }
+        st.gbits = gbits;
+        st.guide_off = (uint32_t)t->guide.size();
+        const uint32_t K = 1u << gbits;
+        for (uint32_t k = 0; k < K; ++k) {
+            double frac = (double)k / (double)K;  // exact
+            double y = st.total * frac;           // one rounding, like total*r on the device
+            uint32_t lo = (uint32_t)(std::upper_bound(cum, cum + L, y) - cum);
+            if (lo > L - 1) lo = L - 1;
+            t->guide.push_back((uint32_t)e0 + lo);
+        }
+        t->guide.push_back((uint32_t)e0 + L - 1);
+        if (t->guide.size() >= 0xFFFFFFF0ull) {
+            mc_set_error("guide table exceeds 2^32 words; lower guide_factor");
+            delete t;
+            return MC_ERR_TABLE;
+        }
+        // payloads with next-state links
+        for (uint64_t e = e0; e < e1; ++e) {
+            uint32_t s = d->ent_sym[e];
+            seq.assign(d->ctx_units + ca, d->ctx_units + ca + cn);
+            if (d->sym_unit_off) {
+                for (uint32_t q = d->sym_unit_off[s]; q < d->sym_unit_off[s + 1]; ++q) seq.push_back(d->sym_units[q]);
+            } else {
+                seq.push_back(s);
+            }
+            mc_payload &p = t->payload[e];
+            p.ml2p = d->ent_ml2p[e];
+            p.next = state_of(seq.data(), (uint32_t)seq.size());
+            p.sym = s | (s == d->end_sym ? 0x80000000u : 0u);
+        }
+    }
+
+    // ---- (row, symbol) -> entry hash ------------------------------------------------------
+    uint64_t cap = pow2ceil(std::max<uint64_t>(16, 2ull * d->n_ent));
+    t->trans.assign(cap, mc_slot{~0ull, 0, 0});
+    for (uint32_t r = 0; r < d->n_ctx; ++r)
+        for (uint64_t e = d->row_off[r]; e < d->row_off[r + 1]; ++e) {
+            uint64_t key = ((uint64_t)r << 32) | d->ent_sym[e];
+            for (uint64_t i = mc_trans_hash(key) & (cap - 1);; i = (i + 1) & (cap - 1)) {
+                mc_slot &s = t->trans[i];
+                if (s.key == ~0ull) {
+                    s = mc_slot{key, (uint32_t)e, 0};
+                    break;
+                }
+                if (s.key == key) {
+                    mc_set_error("row %u lists symbol %u twice", r, d->ent_sym[e]);
+                    delete t;
+                    return MC_ERR_TABLE;
+                }
+            }
+        }
+    *out = t;
+    return MC_OK;
+}
+
+extern "C" void mc_table_free(mc_table *t) { delete t; }
+
+extern "C" int64_t mc_table_array(const mc_table *t, int what, void *dst, size_t cap) {
+    if (!t) return MC_ERR_ARG;
+    const void *src = nullptr;
+    size_t bytes = 0;
+    switch (what) {
+        case MC_ARR_STATE: src = t->state.data(); bytes = t->state.size() * sizeof(mc_state_rec); break;
+        case MC_ARR_GUIDE: src = t->guide.data(); bytes = t->guide.size() * sizeof(uint32_t); break;
+        case MC_ARR_CUM: src = t->cum.data(); bytes = t->cum.size() * sizeof(double); break;
+        case MC_ARR_PAYLOAD: src = t->payload.data(); bytes = t->payload.size() * sizeof(mc_payload); break;
+        case MC_ARR_TRANS: src = t->trans.data(); bytes = t->trans.size() * sizeof(mc_slot); break;
+        case MC_ARR_CTXHASH: src = t->ctxhash.data(); bytes = t->ctxhash.size() * sizeof(mc_slot); break;
+        case MC_ARR_SYMCHARS: src = t->sym_chars.data(); bytes = t->sym_chars.size() * sizeof(uint32_t); break;
+        default: mc_set_error("mc_table_array: unknown array %d", what); return MC_ERR_ARG;
+    }
+    if (dst && cap) std::memcpy(dst, src, std::min(cap, bytes));
+    return (int64_t)bytes;
+}
+
+extern "C" int mc_table_info(const mc_table *t, uint64_t info[16]) {
+    if (!t || !info) return MC_ERR_ARG;
+    std::memset(info, 0, 16 * sizeof(uint64_t));
+    info[MC_INFO_NCTX] = t->n_ctx;
+    info[MC_INFO_NENT] = t->n_ent;
+    info[MC_INFO_NSYM] = t->n_sym;
+    info[MC_INFO_START_STATE] = t->start_state;
+    info[MC_INFO_ROOT] = t->root;
+    info[MC_INFO_TRANS_CAP] = t->trans.size();
+    info[MC_INFO_CTX_CAP] = t->ctxhash.size();
+    info[MC_INFO_GUIDE_LEN] = t->guide.size();
+    info[MC_INFO_DEVICE_BYTES] = mc_table_device_bytes(t);
+    info[MC_INFO_MAX_ROW] = t->max_row;
+    info[MC_INFO_KIND] = t->kind;
+    info[MC_INFO_MULTICHAR] = t->multichar ? 1 : 0;
+    return MC_OK;
+}
+
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+size_t mc_table_device_bytes(const mc_table *t) {
+    return align256(t->state.size() * sizeof(mc_state_rec)) + align256(t->guide.size() * sizeof(uint32_t)) +
+           align256(t->cum.size() * sizeof(double)) + align256(t->payload.size() * sizeof(mc_payload)) +
+           align256(t->trans.size() * sizeof(mc_slot)) + align256(t->ctxhash.size() * sizeof(mc_slot)) +
+           align256(t->sym_chars.size() * sizeof(uint32_t)) + align256(MC_STATUS_WORDS * sizeof(uint64_t));
+}

@@ -1,0 +1,135 @@
+"""Device-side objects behind the lib4mc classes: a model resident on one GPU
+and a rank index built from sampled keys.  torch is used for device memory and
+streams only; every computation is a libmi355mc.so kernel on torch's current
+stream.  No CPU fallback: constructing these without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _native as nv
+from .tables import FlatTable
+
+DEFAULT_MAX_DRAWS = 1 << 16
+CNT_NAMES = ("draws", "cdf_probes", "restarts", "failed", "score_probes", "score_steps", "_6", "_7")
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("montecarlo_amd runs its hot path on an MI355X only: no GPU is visible and there is "
+                           "no CPU fallback")
+
+
+def _vp(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
+
+
+class DeviceModel:
+    def __init__(self, flat: FlatTable, device: Optional[int] = None):
+        _require_gpu()
+        self.flat = flat
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        h = C.c_void_p()
+        nv.check(nv.lib.mc_model_upload(flat.handle, self.device, C.byref(h)))
+        self._h = h
+        self.tdev = torch.device("cuda", self.device)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            nv.lib.mc_model_destroy(h)
+            self._h = None
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.tdev).cuda_stream)
+
+    def check(self) -> dict:
+        """Synchronise, fetch-and-clear the device counters, raise if a sample diverged."""
+        cnt = (C.c_uint64 * 8)()
+        rc = nv.lib.mc_model_check(self._h, self._stream(), cnt)
+        out = dict(zip(CNT_NAMES, list(cnt)))
+        nv.check(rc)
+        return out
+
+    def sample(self, count: int, seed: int, first_id: int = 0, max_draws: int = DEFAULT_MAX_DRAWS,
+               want_len: bool = False, want_draws: bool = False, sym_stride: int = 0, out: torch.Tensor = None):
+        """Launch the sampling kernel; returns dict(ml2p=, len=, draws=, syms=) of device tensors."""
+        with torch.cuda.device(self.tdev):
+            ml2p = out if out is not None else torch.empty(count, dtype=torch.float64, device=self.tdev)
+            assert ml2p.numel() >= count and ml2p.dtype == torch.float64 and ml2p.is_contiguous()
+            ln = torch.empty(count, dtype=torch.int32, device=self.tdev) if (want_len or sym_stride) else None
+            dr = torch.empty(count, dtype=torch.int32, device=self.tdev) if want_draws else None
+            sy = torch.zeros((count, sym_stride), dtype=torch.int32, device=self.tdev) if sym_stride else None
+            nv.check(nv.lib.mc_sample(self._h, first_id, count, seed & 0xFFFFFFFFFFFFFFFF, max_draws, _vp(ml2p),
+                                      _vp(ln), _vp(dr), _vp(sy), sym_stride, self._stream()))
+        return {"ml2p": ml2p, "len": ln, "draws": dr, "syms": sy}
+
+    def sample_injected(self, uniforms, want_draws: bool = True, sym_stride: int = 0):
+        """Parity mode: ``uniforms[i, k]`` is the k-th uniform of sample i."""
+        u = torch.as_tensor(np.ascontiguousarray(uniforms, dtype=np.float64)) if not torch.is_tensor(uniforms) \
+            else uniforms
+        u = u.to(self.tdev, dtype=torch.float64).contiguous()
+        count, dps = u.shape
+        with torch.cuda.device(self.tdev):
+            ml2p = torch.empty(count, dtype=torch.float64, device=self.tdev)
+            ln = torch.empty(count, dtype=torch.int32, device=self.tdev)
+            dr = torch.empty(count, dtype=torch.int32, device=self.tdev) if want_draws else None
+            sy = torch.zeros((count, sym_stride), dtype=torch.int32, device=self.tdev) if sym_stride else None
+            nv.check(nv.lib.mc_sample_injected(self._h, count, _vp(u), dps, _vp(ml2p), _vp(ln), _vp(dr), _vp(sy),
+                                               sym_stride, self._stream()))
+            torch.cuda.current_stream(self.tdev).synchronize()   # `u` must outlive the kernel
+        return {"ml2p": ml2p, "len": ln, "draws": dr, "syms": sy}
+
+    def score_ids(self, syms: np.ndarray, off: np.ndarray, out: torch.Tensor = None) -> torch.Tensor:
+        count = len(off) - 1
+        with torch.cuda.device(self.tdev):
+            d_syms = torch.from_numpy(np.ascontiguousarray(syms, dtype=np.uint32).view(np.int32)).to(self.tdev)
+            d_off = torch.from_numpy(np.ascontiguousarray(off, dtype=np.uint64).view(np.int64)).to(self.tdev)
+            return self.score_device(d_syms, d_off, count, out)
+
+    def score_device(self, d_syms: torch.Tensor, d_off: torch.Tensor, count: int, out: torch.Tensor = None):
+        with torch.cuda.device(self.tdev):
+            res = out if out is not None else torch.empty(count, dtype=torch.float64, device=self.tdev)
+            nv.check(nv.lib.mc_score(self._h, _vp(d_syms), _vp(d_off), count, _vp(res), self._stream()))
+        return res
+
+
+class DeviceRank:
+    """Sorted keys + positions on one GPU (MonteCarloLib.__init__, lib4mc/MonteCarloLib.py:10-28)."""
+
+    def __init__(self, keys: torch.Tensor, n_global: Optional[int] = None, workspace: torch.Tensor = None,
+                 keys_sorted: torch.Tensor = None, positions: torch.Tensor = None):
+        _require_gpu()
+        assert keys.is_cuda and keys.dtype == torch.float64 and keys.is_contiguous()
+        self.n = keys.numel()
+        self.n_global = self.n if n_global is None else int(n_global)
+        self.tdev = keys.device
+        with torch.cuda.device(self.tdev):
+            need = nv.lib.mc_rank_workspace_bytes(self.n)
+            ws = workspace if workspace is not None else torch.empty(need, dtype=torch.uint8, device=self.tdev)
+            self.keys_sorted = keys_sorted if keys_sorted is not None else torch.empty_like(keys)
+            self.positions = positions if positions is not None else torch.empty_like(keys)
+            nv.check(nv.lib.mc_rank_build(_vp(keys), self.n, self.n_global, _vp(self.keys_sorted),
+                                          _vp(self.positions), _vp(ws), ws.numel(),
+                                          C.c_void_p(torch.cuda.current_stream(self.tdev).cuda_stream)))
+            self._ws = ws
+
+    def query(self, x: torch.Tensor, out_pos: torch.Tensor = None, out_cnt: torch.Tensor = None):
+        """(pos, cnt): cnt = bisect_right(sorted, x), pos = positions[cnt-1] (0.0 when cnt == 0)."""
+        assert x.is_cuda and x.dtype == torch.float64 and x.is_contiguous()
+        t = x.numel()
+        with torch.cuda.device(self.tdev):
+            pos = out_pos if out_pos is not None else torch.empty(t, dtype=torch.float64, device=self.tdev)
+            cnt = out_cnt if out_cnt is not None else torch.empty(t, dtype=torch.int64, device=self.tdev)
+            nv.check(nv.lib.mc_rank_query(_vp(self.keys_sorted), _vp(self.positions), self.n, _vp(x), t, _vp(pos),
+                                          _vp(cnt), C.c_void_p(torch.cuda.current_stream(self.tdev).cuda_stream)))
+        return pos, cnt
+
+
+def log2_n(n: int) -> float:
+    return math.log2(n)

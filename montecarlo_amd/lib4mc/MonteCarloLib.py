@@ -1,0 +1,109 @@
+"""Guess-number estimation with the reference's entry points
+(lib4mc/MonteCarloLib.py:9-68): the sampled -log2 p are sorted, turned into the
+running sum of 1/(n*p), and a test password's -log2 p is bisected into it.
+
+Here the sort (radix), the running sum (prefix scan) and the bisection (one lane
+per test password) are HIP kernels; keys and positions stay on the GPU.  With
+``group`` (a torch.distributed process group) the instance holds one shard of
+the samples and queries all-reduce the per-shard partial sums.
+"""
+from math import ceil
+from typing import List, TextIO, Tuple
+
+import numpy
+import torch
+
+from ..engine import DeviceRank
+from .MonteCarloParent import SampleKeys
+
+
+class MonteCarloLib:
+    def __init__(self, minus_log_prob_list, group=None, n_global: int = None):
+        if isinstance(minus_log_prob_list, SampleKeys):
+            keys = minus_log_prob_list.tensor
+        elif torch.is_tensor(minus_log_prob_list):
+            keys = minus_log_prob_list
+        else:
+            keys = torch.tensor(minus_log_prob_list, dtype=torch.float64).cuda()
+        keys = keys.contiguous()
+        self.__group = group
+        if group is not None and n_global is None:
+            n = torch.tensor([keys.numel()], dtype=torch.int64, device=keys.device)
+            torch.distributed.all_reduce(n, group=group)
+            n_global = int(n.item())
+        self.__rank = DeviceRank(keys, n_global=n_global)
+        # the reference sorts the caller's list in place (:11); keep that side effect
+        if isinstance(minus_log_prob_list, SampleKeys):
+            minus_log_prob_list._replace(self.__rank.keys_sorted)
+        elif isinstance(minus_log_prob_list, list):
+            minus_log_prob_list[:] = self.__rank.keys_sorted.cpu().numpy().tolist()
+        self.__gc = None
+
+    @property
+    def device_rank(self) -> DeviceRank:
+        return self.__rank
+
+    def __estimates(self, xs) -> Tuple[numpy.ndarray, numpy.ndarray]:
+        """positions[idx-1] (0 where idx == 0) and idx for every x, summed over shards."""
+        x = torch.as_tensor(numpy.asarray(xs, dtype=numpy.float64)).to(self.__rank.tdev)
+        pos, cnt = self.__rank.query(x.contiguous())
+        if self.__group is not None:
+            torch.distributed.all_reduce(pos, group=self.__group)
+            torch.distributed.all_reduce(cnt, group=self.__group)
+        return pos.cpu().numpy(), cnt.cpu().numpy()
+
+    def ml2p2rank(self, minus_log_prob):
+        pos, cnt = self.__estimates([minus_log_prob])
+        return pos[0] if cnt[0] > 0 else 1
+
+    def ml2p_iter2gc(self, minus_log_prob_iter: List[Tuple[str, int, float]],
+                     need_resort: bool = False, add1: bool = True) \
+            -> List[Tuple[str, float, int, int, int, float]]:
+        if need_resort:
+            minus_log_prob_iter = sorted(minus_log_prob_iter, key=lambda x: x[2])
+        items = list(minus_log_prob_iter)
+        if not items:
+            self.__gc = []
+            return self.__gc
+        pwds = [t[0] for t in items]
+        apps = [t[1] for t in items]
+        mlps = [t[2] for t in items]
+        pos, cnt = self.__estimates(mlps)
+        est = numpy.where(cnt > 0, pos, 1.0)
+        ranks = _monotone_ranks(est, cnt, add1)
+        total = sum(apps)
+        cracked, run = [], 0
+        for a in apps:
+            run += a
+            cracked.append(run)
+        gc = [(p, m, a, r, c, c / total * 100) for p, m, a, r, c in zip(pwds, mlps, apps, ranks, cracked)]
+        self.__gc = gc
+        return gc
+
+    def write2(self, fd: TextIO):
+        if not fd.writable():
+            raise Exception(f"{fd.name} is not writable")
+        if self.__gc is None:
+            raise Exception(f"run mlps2gc before invoke this method")
+        fd.writelines(f"{pwd}\t{mlp:.8f}\t{appearance}\t{rank}\t{cracked}\t{cracked_ratio:5.2f}\n"
+                      for pwd, mlp, appearance, rank, cracked, cracked_ratio in self.__gc)
+        self.__gc = None
+
+
+def _monotone_ranks(est: numpy.ndarray, cnt: numpy.ndarray, add1: bool) -> List[int]:
+    """rank_i = ceil(max(est_i, rank_{i-1} + add)), rank_0 = 0 (reference :47-55).
+    While every value is below 2^52 (float and int comparisons exact) this is a running
+    maximum; beyond that it is evaluated with the reference's own expression, whose
+    numpy-float-vs-int comparisons are themselves lossy there."""
+    if est.size and numpy.all(numpy.isfinite(est)) and float(est.max()) < 2.0 ** 52:
+        c = numpy.ceil(est).astype(numpy.int64)
+        if add1:
+            i = numpy.arange(1, c.size + 1, dtype=numpy.int64)
+            s = numpy.maximum.accumulate(numpy.maximum(c - i, 0))
+            return (s + i).tolist()
+        return numpy.maximum.accumulate(numpy.maximum(c, 0)).tolist()
+    out, prev, step = [], 0, 1 if add1 else 0
+    for e, k in zip(est, cnt):
+        prev = ceil(max(e if k > 0 else 1, prev + step))
+        out.append(prev)
+    return out

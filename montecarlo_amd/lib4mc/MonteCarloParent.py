@@ -1,0 +1,161 @@
+"""The plugin base class, with the reference's surface
+(lib4mc/MonteCarloParent.py:11-69): ``minus_log2``, abstract ``calc_ml2p`` /
+``sample1``, batch ``sample`` and ``parse_file``.
+
+What changed is the inside: a subclass that attaches a compiled table
+(``self._flat`` / ``self._dev``, see montecarlo_amd.models) gets ``sample`` and
+``parse_file`` executed as HIP kernels over the whole batch.  A third-party
+subclass that only overrides ``sample1`` / ``calc_ml2p`` still works through the
+per-item loops, exactly like the reference -- that is the plugin's own code, not
+a fallback of the engine.
+"""
+import abc
+import collections.abc
+import random
+from math import log2
+from typing import Dict, List, TextIO, Tuple, Union
+
+import numpy as np
+
+from .FileLib import wc_l
+
+
+class SampleKeys(collections.abc.Sequence):
+    """The list ``sample`` returns: -log2 p of every sample in draw order, kept on
+    the GPU.  It behaves as a read-only sequence of floats (materialised on first
+    element access); ``MonteCarloLib`` consumes it without a host round trip.
+    10^7..10^10 keys cannot be a Python list."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+        self._host = None
+
+    def __len__(self):
+        return int(self.tensor.numel())
+
+    def _materialise(self):
+        if self._host is None:
+            self._host = self.tensor.cpu().numpy()
+        return self._host
+
+    def __getitem__(self, i):
+        v = self._materialise()[i]
+        return v.tolist() if isinstance(i, slice) else float(v)
+
+    def __iter__(self):
+        return iter(self._materialise().tolist())
+
+    def tolist(self) -> List[float]:
+        return self._materialise().tolist()
+
+    def _replace(self, tensor):
+        self.tensor, self._host = tensor, None
+
+
+class MonteCarlo(metaclass=abc.ABCMeta):
+    _flat = None         # montecarlo_amd.tables.FlatTable once a subclass attaches a compiled table
+    _dev_model = None    # montecarlo_amd.engine.DeviceModel, uploaded on first use
+    _seed = None
+    _next_id = 0
+    max_draws = 1 << 16  # bound on uniforms per sample; the reference has none (it would spin)
+
+    @staticmethod
+    def minus_log2(prob: float) -> float:
+        return -log2(prob)
+
+    @abc.abstractmethod
+    def calc_ml2p(self, pwd: str) -> Tuple[float, List[str]]:
+        return .0, []
+
+    @abc.abstractmethod
+    def sample1(self) -> (float, str):
+        return .0, ""
+
+    @property
+    def _dev(self):
+        if self._dev_model is None:
+            from ..engine import DeviceModel
+            self._dev_model = DeviceModel(self._flat)     # raises without a GPU: no CPU fallback
+        return self._dev_model
+
+    # ---- Philox stream bookkeeping -----------------------------------------------------------
+    def seed(self, seed: int, first_id: int = 0):
+        """Fix the counter-based stream: sample ``i`` of this model always uses
+        uniforms (seed, i, 0..).  Unset, the seed is drawn from ``random`` so that
+        ``random.seed(...)`` makes a run reproducible, as with the reference."""
+        self._seed, self._next_id = int(seed) & 0xFFFFFFFFFFFFFFFF, int(first_id)
+
+    def _claim_ids(self, n: int) -> Tuple[int, int]:
+        if self._seed is None:
+            self._seed = random.getrandbits(64)
+        first = self._next_id
+        self._next_id += n
+        return self._seed, first
+
+    # ---- batch sampling (reference :33-46) -----------------------------------------------------
+    def sample(self, size: int, sampled_pwds: Dict[str, List] = None, clearIfNotNone: bool = True):
+        if self._flat is None:
+            return self._sample_by_loop(size, sampled_pwds, clearIfNotNone)
+        seed, first = self._claim_ids(size)
+        want = isinstance(sampled_pwds, dict)
+        stride = 32 if want else 0
+        res = self._dev.sample(size, seed, first_id=first, max_draws=self.max_draws, sym_stride=stride)
+        self._dev.check()
+        if want:
+            strings = self._strings_of(res, seed, first)
+            ml2p = res["ml2p"].cpu().numpy().tolist()
+            seen: Dict[str, List] = {}
+            for x, pwd in zip(ml2p, strings):
+                hit = seen.get(pwd)
+                if hit is None:
+                    seen[pwd] = [x, 1]
+                else:
+                    hit[1] += 1
+            if clearIfNotNone:
+                sampled_pwds.clear()
+            sampled_pwds.update(seen)
+        return SampleKeys(res["ml2p"])
+
+    def _strings_of(self, res, seed: int, first: int) -> List[str]:
+        lens = res["len"].cpu().numpy()
+        syms = res["syms"].cpu().numpy()
+        stride = syms.shape[1]
+        drop = getattr(self, "start_chr", "") or ""
+        out = self._flat.decode(syms, np.minimum(lens, stride), drop=drop)
+        for i in np.nonzero(lens > stride)[0]:       # rare long strings: replay that sample id alone
+            one = self._dev.sample(1, seed, first_id=first + int(i), max_draws=self.max_draws,
+                                   sym_stride=int(lens[i]))
+            out[i] = self._flat.decode(one["syms"].cpu().numpy(), one["len"].cpu().numpy(), drop=drop)[0]
+        return out
+
+    def _sample_by_loop(self, size, sampled_pwds, clearIfNotNone):
+        results, seen = [], {}
+        for _ in range(size):
+            prob, pwd = self.sample1()
+            results.append(prob)
+            seen.setdefault(pwd, [prob, 0])[1] += 1
+        if isinstance(sampled_pwds, dict):
+            if clearIfNotNone:
+                sampled_pwds.clear()
+            sampled_pwds.update(seen)
+        return results
+
+    # ---- test-set scoring (reference :48-69) ---------------------------------------------------
+    def score_batch(self, pwds: List[str]):
+        """(ml2p list, components list) for many passwords; models with a device table
+        override this with one kernel launch."""
+        pairs = [self.calc_ml2p(p) for p in pwds]
+        return [m for m, _ in pairs], [c for _, c in pairs]
+
+    def parse_file(self, testing_set: TextIO, using_component: bool = False) \
+            -> List[Tuple[Union[str, List[str]], int, float]]:
+        wc_l(testing_set)                                   # rewinds, as the reference does
+        counts: Dict[str, int] = {}
+        for line in testing_set:
+            line = line.strip("\r\n")
+            counts[line] = counts.get(line, 0) + 1
+        pwds = list(counts)
+        ml2p, parts = self.score_batch(pwds)
+        order = np.argsort(np.asarray(ml2p, dtype=np.float64), kind="stable")
+        first = parts if using_component else pwds
+        return [(first[i], counts[pwds[i]], ml2p[i]) for i in order.tolist()]

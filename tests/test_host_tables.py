@@ -1,0 +1,149 @@
+"""CPU tests of the host side of the product: trainers reproduce the reference's
+tables (golden digests), the C-ABI library loads and exports every declared
+symbol, and the compiled walk automaton -- stepped by tests/walker.py exactly as
+the HIP kernels step it -- reproduces the reference's samples and scores."""
+import ctypes
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, fh, golden, golden_lines, hx
+from montecarlo_amd import _native as nv
+from montecarlo_amd import synth
+from montecarlo_amd.backwords.backwords_secondary_trainer import backwords_counter as secondary_counter
+from montecarlo_amd.backwords_secondary_simulator import BackWordsSecondaryMonteCarlo
+from montecarlo_amd.backwords_simulator import BackWordsMonteCarlo
+from montecarlo_amd.nwords_simulator import NWordsMonteCarlo
+from montecarlo_amd.nwords_simulator_v2 import NWords2MonteCarlo
+from oracle.philox import SampleStream
+from walker import CompiledWalker
+
+
+def rows_of(table):
+    return [[ctx if isinstance(ctx, str) else list(ctx), list(keys), [hx(vals[k]) for k in keys],
+             [hx(c) for c in cum]] for ctx, (vals, keys, cum) in table.items()]
+
+
+def digest(obj):
+    return hashlib.sha256(json.dumps(obj, ensure_ascii=True, separators=(",", ":")).encode()).hexdigest()
+
+
+def test_library_exports_header_symbols():
+    hdr = open(os.path.join(ROOT, "include", "mi355mc.h")).read()
+    declared = set(re.findall(r"\b(mc_[a-z0-9_]+)\s*\(", hdr)) - {"mc_table_info_idx"}
+    assert declared == set(nv.EXPORTS), declared ^ set(nv.EXPORTS)
+    lib = ctypes.CDLL(nv.LIB_PATH)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert nv.lib.mc_abi_version() == 1
+
+
+def check_table(fx, model):
+    rows = rows_of(model.nwords)
+    assert len(rows) == fx["n_ctx"]
+    assert rows[:len(fx["rows_head"])] == fx["rows_head"]
+    assert digest(rows) == fx["table_digest"]
+    if "words_digest" in fx:
+        assert digest(sorted(model.words.items())) == fx["words_digest"]
+    assert model._flat.info[nv.INFO_NCTX] == fx["n_ctx"]
+    assert model._flat.info[nv.INFO_NENT] == fx["n_entries"]
+
+
+def check_walk(fx, model, n_samples=150, n_scores=None, keep_len=False):
+    flat = model._flat
+    w = CompiledWalker(flat)
+    seed = fx["samples"]["seed"]
+    drop = getattr(model, "start_chr", "")
+    for i, (want, pwd, draws) in enumerate(fx["samples"]["items"][:n_samples]):
+        st = SampleStream(seed, i)
+        acc, syms, used = w.sample(st, keep_len=keep_len)
+        got = "".join(c for c in (flat.symbols[s] for s in syms) if c != drop)
+        assert (hx(acc), got, used) == (want, pwd, draws), i
+    if "scores" in fx and not flat.multichar:
+        for pwd, want, _parts in fx["scores"][:n_scores]:
+            ids, _ = flat.encode_chars([pwd])
+            got = w.score(ids.tolist(), flat.end_sym, len(flat.symbols))
+            assert hx(got) == want, repr(pwd)
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_nwords_char(train_char, n):
+    fx = golden(f"nwords_n{n}_char.json")
+    m = NWordsMonteCarlo(synth.as_file(train_char), n=n, splitter="")
+    check_table(fx, m)
+    check_walk(fx, m)
+
+
+def test_nwords_tab(train_tab):
+    fx = golden("nwords_n3_tab.json")
+    m = NWordsMonteCarlo(synth.as_file(train_tab), n=3, splitter="\t")
+    check_table(fx, m)
+    assert m._flat.multichar
+    check_walk(fx, m)
+
+
+@pytest.mark.parametrize("thr", [2, 10])
+def test_backwords_char(train_char, thr):
+    fx = golden(f"backwords_thr{thr}_char.json")
+    m = BackWordsMonteCarlo(synth.as_file(train_char), splitter="", threshold=thr)
+    check_table(fx, m)
+    check_walk(fx, m, n_samples=250)
+
+
+def test_backwords_tab(train_tab):
+    fx = golden("backwords_thr3_tab.json")
+    m = BackWordsMonteCarlo(synth.as_file(train_tab), splitter="\t", threshold=3)
+    check_table(fx, m)
+    check_walk(fx, m)
+
+
+def test_secondary(train_char):
+    fx = golden("secondary_thr4_char.json")
+    cfg = {"start_chr": "\x03", "end_chr": "\x00", "threshold": 4}
+    counts, words = secondary_counter(train_char[:2500], "", "\x03", "\x00", 0, 1, 256, 4)
+    m = BackWordsSecondaryMonteCarlo((counts, words, cfg))
+    check_table(fx["round0"], m)
+    check_walk(fx["round0"], m, n_samples=100)
+    counts, words = secondary_counter(train_char[2500:3200], "", "\x03", "\x00", 0, 1, 256, 4, nwords_dict=counts,
+                                      words=words)
+    assert digest([[list(k), sorted(v.items())] for k, v in counts.items()]) == fx["meta"]["counts_digest"]
+    m = BackWordsSecondaryMonteCarlo((counts, words, cfg))
+    check_table(fx["round1"], m)
+    check_walk(fx["round1"], m, n_samples=100)
+
+
+def test_v2(train_v2):
+    fx = golden("v2_n4.json")
+    m = NWords2MonteCarlo(synth.as_file(train_v2), 4)
+    check_table(fx, m)
+    check_walk(fx, m, keep_len=True)
+
+
+def test_guide_brackets_bisect(train_char):
+    """Every guide bucket [lo, hi] contains bisect_right(cum, total*r) for r at the
+    bucket's edges and just inside them (the exactness argument of mc_table.cpp)."""
+    m = BackWordsMonteCarlo(synth.as_file(train_char), splitter="", threshold=10)
+    w = CompiledWalker(m._flat)
+    rng = np.random.default_rng(5)
+    for r_ in rng.choice(len(w.state), size=300, replace=False):
+        rec = w.state[r_]
+        e0, L, K = int(rec["ent_off"]), int(rec["len"]), 1 << int(rec["gbits"])
+        cum = w.cum[e0:e0 + L]
+        for k in range(K):
+            lo, hi = int(w.guide[int(rec["guide_off"]) + k]) - e0, int(w.guide[int(rec["guide_off"]) + k + 1]) - e0
+            for r in (k / K, np.nextafter((k + 1) / K, 0.0), (k + 0.5) / K):
+                idx = min(int(np.searchsorted(cum, float(rec["total"]) * r, side="right")), L - 1)
+                assert lo <= idx <= hi
+
+
+def test_compile_rejects_bad_tables():
+    from montecarlo_amd.lib4mc.ProbLib import expand_2d
+    from montecarlo_amd.tables import FlatTable
+    # ("a","b") is a row but ("a",) is not: the backoff automaton would not be exact
+    table = expand_2d({(): {"a": .5, "\x03": .5}, ("a", "b"): {"\x03": 1.0}})
+    with pytest.raises(nv.NativeError, match="prefix-closed"):
+        FlatTable(table, nv.KIND_BACKOFF, start_units=("\x00",))

@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BASELINE.json configs[1] -- backwords char-level backoff model
+(threshold 10) trained on 100k synthetic Zipfian passwords; one "step" = the whole
+guess-number hot path on one GPU:
+
+    sample N=1e7 strings (k_sample) -> radix sort + prefix sum of 1/(n p) (mc_rank_build)
+    -> score T=1e6 test passwords (k_score) -> bisect them into the curve (k_query)
+    [-> all-reduce of the per-test partial sums when world_size > 1]
+
+Inputs (compiled tables, encoded test set) are resident in HBM before the timed region.
+Prints ONE JSON line on rank 0.  `python bench.py --gpus N --steps K --warmup W`; for N > 1
+launch through torch.distributed.run (one rank per GPU, weak scaling: every GPU draws N).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("TQDM_DISABLE", "1")
+
+from montecarlo_amd import synth  # noqa: E402
+from montecarlo_amd.backwords_simulator import BackWordsMonteCarlo  # noqa: E402
+from montecarlo_amd.engine import DeviceRank  # noqa: E402
+from montecarlo_amd import _native as nv  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+# algorithmic bytes of one draw in k_sample (DESIGN.md "Sampling kernel"): state record 32 B,
+# guide bucket 8 B, payload 16 B, plus 8 B per cum[] comparison; 8 B key written per sample
+B_DRAW, B_PROBE, B_SAMPLE = 32 + 8 + 16, 8, 8
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--samples", type=int, default=10_000_000, help="samples per GPU per step")
+    ap.add_argument("--tests", type=int, default=1_000_000)
+    ap.add_argument("--train-lines", type=int, default=100_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-samples", type=int, default=300_000)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    # ---------------- model + inputs (untimed) ----------------
+    N, T = args.samples, args.tests
+    train = synth.zipf_corpus(args.train_lines)
+    model = BackWordsMonteCarlo(synth.as_file(train), splitter="", threshold=10)
+    flat, dm = model._flat, model._dev
+    test = synth.zipf_corpus(T, oov_frac=0.01, stream=1)
+    syms, off = flat.encode_chars(test)
+    d_syms = torch.from_numpy(syms.view(np.int32)).to(dev)
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    keys = torch.empty(N, dtype=torch.float64, device=dev)
+    keys_sorted = torch.empty_like(keys)
+    positions = torch.empty_like(keys)
+    ws = torch.empty(nv.lib.mc_rank_workspace_bytes(N), dtype=torch.uint8, device=dev)
+    t_ml2p = torch.empty(T, dtype=torch.float64, device=dev)
+    q_pos = torch.empty(T, dtype=torch.float64, device=dev)
+    q_cnt = torch.empty(T, dtype=torch.int64, device=dev)
+    seed = 20250304
+
+    ev = {k: [] for k in ("sample", "rank", "score", "query")}
+
+    def step(it: int, timed: bool):
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        first = (it * world + rank) * N                     # disjoint Philox sample ids per rank and step
+        marks[0].record()
+        dm.sample(N, seed, first_id=first, out=keys)
+        marks[1].record()
+        rk = DeviceRank(keys, n_global=N * world, workspace=ws, keys_sorted=keys_sorted, positions=positions)
+        marks[2].record()
+        dm.score_device(d_syms, d_off, T, out=t_ml2p)
+        marks[3].record()
+        rk.query(t_ml2p, out_pos=q_pos, out_cnt=q_cnt)
+        if world > 1:
+            dist.all_reduce(q_pos)
+            dist.all_reduce(q_cnt)
+        marks[4].record()
+        if timed:
+            ev["sample"].append((marks[0], marks[1]))
+            ev["rank"].append((marks[1], marks[2]))
+            ev["score"].append((marks[2], marks[3]))
+            ev["query"].append((marks[3], marks[4]))
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        step(w, False)
+    torch.cuda.synchronize()
+    dm.check()                                              # clears counters; raises on a diverged sample
+    fence()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        step(args.warmup + s, True)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    cnt = dm.check()
+    ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
+
+    # sanity on the last step (not timed): finite keys, sorted output
+    assert bool(torch.isfinite(keys).all()) and bool((keys_sorted[1:] >= keys_sorted[:-1]).all())
+
+    if rank == 0:
+        draws, probes = cnt["draws"] / args.steps, cnt["cdf_probes"] / args.steps
+        bytes_per_launch = draws * B_DRAW + probes * B_PROBE + N * B_SAMPLE
+        achieved = bytes_per_launch / (ms["sample"] * 1e-3) / 1e9
+        out = {
+            "metric": "sampled passwords/sec (node) + guess numbers/sec, 4-gram backoff, 1/2/4/8 GPU",
+            "value": N * world * args.steps / dt,
+            "unit": "sampled passwords/s (through sample+sort+scan+score+rank)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[1]: backwords char-level backoff (threshold 10, 100k synthetic Zipf "
+                                   "training lines), 1e7 samples + 1e6 test pwds per GPU per step",
+                       "samples_per_gpu": N, "test_pwds": T, "contexts": int(flat.info[nv.INFO_NCTX]),
+                       "entries": int(flat.info[nv.INFO_NENT]), "table_bytes": int(flat.info[nv.INFO_DEVICE_BYTES])},
+            "stage_ms": ms,
+            "sampling_only_per_s": N * world / (ms["sample"] * 1e-3),
+            "guess_numbers_per_s": T / ((ms["score"] + ms["query"]) * 1e-3),
+            "draws_per_sample": draws / N, "cdf_probes_per_draw": probes / max(draws, 1),
+            "roofline": {"bound": "hbm", "kernel": "k_sample", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_launch": bytes_per_launch, "kernel_ms": ms["sample"]},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(model, test, args.cpu_samples)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(model, test, n_samples: int):
+    """The C restatement of the reference's algorithm (oracle/mc_oracle.c), one host thread, on a
+    bounded sample of the same workload: n_samples samples + their rank build + 1/10 as many
+    test passwords scored and ranked."""
+    from oracle import c_oracle
+    cm = c_oracle.COracleModel(model.nwords, c_oracle.KIND_BACKOFF, start_units=["\x00"])
+    t_n = max(1000, n_samples // 10)
+    t0 = time.perf_counter()
+    res = cm.sample(n_samples, 20250304)
+    t1 = time.perf_counter()
+    srt, pos = c_oracle.rank_build(res["ml2p"])
+    t2 = time.perf_counter()
+    sc = cm.score(test[:t_n])
+    t3 = time.perf_counter()
+    c_oracle.rank_query(srt, pos, np.sort(sc))
+    t4 = time.perf_counter()
+    return {"value": n_samples / (t4 - t0), "unit": "sampled passwords/s (same pipeline, scaled sample)",
+            "cores": 1, "kind": "port",
+            "sample": f"{n_samples} samples + rank build + {t_n} test pwds scored/ranked, oracle/mc_oracle.c",
+            "sampling_only_per_s": n_samples / (t1 - t0), "scored_per_s": t_n / (t3 - t2),
+            "rank_build_s": t2 - t1, "reference_python_samples_per_s_build_container": 22988}
+
+
+if __name__ == "__main__":
+    main()

@@ -289,7 +289,7 @@ extern "C" int mc_model_upload(const mc_table *t, int device, mc_model **out) {
     if (e != hipSuccess) {
         mc_set_error("hipMalloc(%zu) failed: %s", m->arena_bytes, hipGetErrorString(e));
         delete m;
-        hipSetDevice(prev);
+        (void)hipSetDevice(prev);
         return MC_ERR_NOMEM;
     }
     HIP_TRY(hipDeviceGetAttribute(&m->n_cu, hipDeviceAttributeMultiprocessorCount, device));

@@ -132,7 +132,6 @@ __global__ void __launch_bounds__(SORT_THREADS) k_count(const Plan *__restrict__
 __global__ void __launch_bounds__(1024) k_scan_counts(const Plan *__restrict__ plan, int pass, u32 *counts, u32 len) {
     if (plan->skip[pass]) return;
     __shared__ u32 wave_tot[16];
-    __shared__ u32 carry_s;
     const u32 per = (len + 1023) / 1024;
     const u32 lo = min(len, threadIdx.x * per), hi = min(len, lo + per);
     u32 sum = 0;
@@ -153,7 +152,6 @@ __global__ void __launch_bounds__(1024) k_scan_counts(const Plan *__restrict__ p
             wave_tot[w] = c;
             c += v;
         }
-        carry_s = c;
     }
     __syncthreads();
     u32 run = wave_tot[wid] + inc - sum;
@@ -361,7 +359,8 @@ extern "C" size_t mc_rank_workspace_bytes(uint64_t n) {
 extern "C" int mc_rank_build(const double *keys_in, uint64_t n, uint64_t n_global, double *keys_sorted,
                              double *positions, void *workspace, size_t workspace_bytes, void *stream) {
     if (n == 0) return MC_OK;
-    if (!keys_in || !keys_sorted || !positions || !workspace || n_global < n) {
+    if (!keys_in || !keys_sorted || !positions || !workspace || n_global < n || keys_in == keys_sorted ||
+        (const void *)positions == (const void *)keys_sorted) {
         mc_set_error("mc_rank_build: bad argument");
         return MC_ERR_ARG;
     }

@@ -222,6 +222,15 @@ def main():
         "gc_add0_ranks": [str(t[3]) for t in gc0],
         "write2": buf.getvalue()})
 
+    # ---------------- distribution of the reference's own Mersenne-Twister sampler ----------------
+    import numpy as np
+    rng = random.Random(777)
+    random.uniform = rng.uniform
+    drawn = [bw10.sample1() for _ in range(20000)]
+    random.uniform = FEED.uniform
+    np.savez_compressed(os.path.join(HERE, "dist_backwords_thr10.npz"),
+                        ml2p=np.array([d[0] for d in drawn]), len=np.array([len(d[1]) for d in drawn]))
+
     # ---------------- reference timings on the config-1 shape (reported baseline) ----------------
     if "--time" in sys.argv:
         time_reference()

@@ -1,0 +1,260 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the
+C-ABI of libmi355mc.so (montecarlo_amd._native via the host classes):
+
+ (a) per-password -log2 p == reference calc_ml2p (golden, bit-exact; tolerance of the
+     north star is 1e-9, the implementation is exact);
+ (b) same uniform stream -> bit-identical strings / ml2p / draw counts as the reference
+     sampler (golden), in Philox mode and in injected-uniform mode;
+ (c) identical sample set -> guess numbers within 1e-9 relative of the reference (golden);
+ (d) sample distribution vs the reference's Mersenne-Twister sampler (KS / chi-square),
+     plus bit-exact agreement with the C oracle on larger runs.
+"""
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import fh, golden, golden_lines, hx
+from montecarlo_amd import synth
+from montecarlo_amd.backwords.backwords_secondary_trainer import backwords_counter as secondary_counter
+from montecarlo_amd.backwords_secondary_simulator import BackWordsSecondaryMonteCarlo
+from montecarlo_amd.backwords_simulator import BackWordsMonteCarlo
+from montecarlo_amd.engine import DeviceRank
+from montecarlo_amd.lib4mc.MonteCarloLib import MonteCarloLib
+from montecarlo_amd.nwords_simulator import NWordsMonteCarlo
+from montecarlo_amd.nwords_simulator_v2 import NWords2MonteCarlo
+from oracle import c_oracle
+from oracle.philox import uniform53
+
+pytestmark = pytest.mark.gpu
+REL = 1e-9      # north-star tolerance for guess numbers
+
+
+def device_samples(model, fx, n=None, injected=False):
+    items = fx["samples"]["items"][:n]
+    seed = fx["samples"]["seed"]
+    dev = model._dev
+    if injected:
+        dmax = max(it[2] for it in items)
+        u = np.array([[uniform53(seed, i, k) for k in range(dmax)] for i in range(len(items))])
+        res = dev.sample_injected(u, sym_stride=300)
+    else:
+        res = dev.sample(len(items), seed, want_draws=True, sym_stride=300)
+    dev.check()
+    strings = model._flat.decode(res["syms"].cpu().numpy(), res["len"].cpu().numpy(),
+                                 drop=getattr(model, "start_chr", ""))
+    got = [[hx(a), s, int(d)] for a, s, d in zip(res["ml2p"].cpu().numpy(), strings, res["draws"].cpu().numpy())]
+    assert got == items
+
+
+def device_scores(model, fx):
+    pw = [s[0] for s in fx["scores"]]
+    ml2p, parts = model.score_batch(pw)
+    assert [hx(x) for x in ml2p] == [s[1] for s in fx["scores"]]
+    assert parts == [s[2] for s in fx["scores"]]
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_nwords_char(train_char, n):
+    fx = golden(f"nwords_n{n}_char.json")
+    m = NWordsMonteCarlo(synth.as_file(train_char), n=n, splitter="")
+    device_samples(m, fx)
+    device_samples(m, fx, n=200, injected=True)
+    device_scores(m, fx)
+
+
+@pytest.mark.parametrize("thr", [2, 10])
+def test_backwords_char(train_char, thr):
+    fx = golden(f"backwords_thr{thr}_char.json")
+    m = BackWordsMonteCarlo(synth.as_file(train_char), splitter="", threshold=thr)
+    device_samples(m, fx)
+    device_samples(m, fx, n=200, injected=True)
+    device_scores(m, fx)
+
+
+def test_subword_sampling(train_tab):
+    m = NWordsMonteCarlo(synth.as_file(train_tab), n=3, splitter="\t")
+    device_samples(m, golden("nwords_n3_tab.json"))
+    m = BackWordsMonteCarlo(synth.as_file(train_tab), splitter="\t", threshold=3)
+    device_samples(m, golden("backwords_thr3_tab.json"))
+
+
+def test_secondary_and_v2(train_char, train_v2):
+    fx = golden("secondary_thr4_char.json")
+    cfg = {"start_chr": "\x03", "end_chr": "\x00", "threshold": 4}
+    counts, words = secondary_counter(train_char[:2500], "", "\x03", "\x00", 0, 1, 256, 4)
+    m = BackWordsSecondaryMonteCarlo((counts, words, cfg))
+    device_samples(m, fx["round0"])
+    device_scores(m, fx["round0"])
+    counts, words = secondary_counter(train_char[2500:3200], "", "\x03", "\x00", 0, 1, 256, 4, nwords_dict=counts,
+                                      words=words)
+    m = BackWordsSecondaryMonteCarlo((counts, words, cfg))
+    device_samples(m, fx["round1"])
+    device_scores(m, fx["round1"])
+    m = NWords2MonteCarlo(synth.as_file(train_v2), 4)
+    device_samples(m, golden("v2_n4.json"))
+
+
+def test_plugin_surface_matches_reference_run(train_char):
+    """sample -> MonteCarloLib -> parse_file -> ml2p_iter2gc -> write2, the whole driver of
+    backwords_simulator.py:90-94, against the reference's recorded run (rank.json)."""
+    fx = golden("rank.json")
+    m = BackWordsMonteCarlo(synth.as_file(train_char), splitter="", threshold=10)
+    m.seed(fx["meta"]["seed"])
+    keys = m.sample(fx["meta"]["n"])
+    assert [hx(x) for x in keys] == fx["draw_order"]
+    mc = MonteCarloLib(keys)
+    assert [hx(x) for x in keys] == fx["sorted"]                       # sorted in place, like the reference
+    pos = mc.device_rank.positions.cpu().numpy()
+    want = np.array([fh(x) for x in fx["positions"]])
+    assert np.all(np.abs(pos - want) <= REL * want)
+    for x, w in fx["probes"]:
+        got = mc.ml2p2rank(fh(x))
+        assert abs(float(got) - fh(w)) <= REL * fh(w)
+    scored = m.parse_file(synth.as_file(golden_lines("test_char.txt")))
+    assert [[p, c, hx(x)] for p, c, x in scored] == fx["scored"]
+    gc = mc.ml2p_iter2gc(scored)
+    for (p, x, c, r, k, ratio), (wp, wx, wc, wr, wk, wratio) in zip(gc, fx["gc"]):
+        assert (p, hx(x), c, k, hx(ratio)) == (wp, wx, wc, wk, wratio)
+        assert abs(r - int(wr)) <= REL * int(wr) + 1e-12, (p, r, wr)
+    exact = sum(1 for g, w in zip(gc, fx["gc"]) if g[3] == int(w[3]))
+    assert exact >= len(gc) - 2                                        # ceil() may flip on an exact integer
+    buf = io.StringIO()
+    mc.write2(buf)
+    if exact == len(gc):
+        assert buf.getvalue() == fx["write2"]
+    gc0 = mc.ml2p_iter2gc(scored, add1=False)
+    assert sum(1 for g, w in zip(gc0, fx["gc_add0_ranks"]) if g[3] == int(w)) >= len(gc0) - 2
+    # list input: uploaded, sorted in place on the device, same numbers
+    lst = [fh(x) for x in fx["draw_order"]]
+    mc2 = MonteCarloLib(lst)
+    assert [hx(x) for x in lst] == fx["sorted"]
+    assert mc2.ml2p2rank(33.3) == mc.ml2p2rank(33.3)
+
+
+# ---------------------------------------------------------------------------------- larger runs
+@pytest.fixture(scope="module")
+def big_model():
+    train = synth.zipf_corpus(100000)
+    m = BackWordsMonteCarlo(synth.as_file(train), splitter="", threshold=10)
+    cm = c_oracle.COracleModel(m.nwords, c_oracle.KIND_BACKOFF, start_units=["\x00"])
+    return m, cm
+
+
+def test_sampling_matches_c_oracle(big_model):
+    m, cm = big_model
+    n, seed, first = 200000, 0xC0FFEE, 12345678901
+    res = m._dev.sample(n, seed, first_id=first, want_len=True, want_draws=True, sym_stride=24)
+    cnt = m._dev.check()
+    want = cm.sample(n, seed, first_id=first, stride=24)
+    assert np.array_equal(res["ml2p"].cpu().numpy().view(np.uint64), want["ml2p"].view(np.uint64))
+    assert np.array_equal(res["draws"].cpu().numpy().astype(np.uint32), want["draws"])
+    assert np.array_equal(res["len"].cpu().numpy().astype(np.uint32), want["len"])
+    assert cnt["draws"] == int(want["draws"].sum()) and cnt["failed"] == 0
+    got_s = m._flat.decode(res["syms"].cpu().numpy(), np.minimum(res["len"].cpu().numpy(), 24))
+    want_s = cm.strings({"syms": want["syms"], "len": np.minimum(want["len"], 24)})
+    assert got_s == want_s
+
+
+def test_launch_geometry_does_not_change_results(big_model):
+    m, _ = big_model
+    a = m._dev.sample(50000, 7, first_id=1000)["ml2p"]
+    b = torch.cat([m._dev.sample(20000, 7, first_id=1000)["ml2p"], m._dev.sample(30000, 7, first_id=21000)["ml2p"]])
+    m._dev.check()
+    assert torch.equal(a.view(torch.int64), b.view(torch.int64))
+
+
+def test_scoring_matches_c_oracle(big_model):
+    m, cm = big_model
+    test = list(dict.fromkeys(synth.zipf_corpus(30000, oov_frac=0.02, stream=1))) + ["", "a" * 300]
+    got, _ = m.score_batch(test)
+    want = cm.score(test)
+    assert np.array_equal(np.array(got).view(np.uint64), want.view(np.uint64))
+    assert 0 < int((want == 1022.0).sum()) < len(test)
+
+
+def test_rank_pipeline_full_size(big_model):
+    """config-2 sizes: 1e7 samples, 1e6 queries -- size-independent properties plus an
+    independent device sort (torch.sort) and a CPU prefix sum on a stride."""
+    m, cm = big_model
+    n = 10_000_000
+    keys = m._dev.sample(n, 99)["ml2p"]
+    m._dev.check()
+    rk = DeviceRank(keys)
+    srt, _ = torch.sort(keys)
+    assert torch.equal(rk.keys_sorted.view(torch.int64), srt.view(torch.int64))
+    pos = rk.positions
+    assert bool((pos[1:] >= pos[:-1]).all())
+    w = torch.exp2(srt - np.log2(n))
+    ref = torch.cumsum(w, 0)
+    assert float(((pos - ref).abs() / ref).max()) < REL
+    total = float(w.sum())
+    assert abs(float(pos[-1]) - total) <= REL * total
+    # queries: sorted test keys, ties, below-min, above-max
+    x = torch.cat([srt[::10][:999000], torch.tensor([0.0, 1e-3, 2000.0, float(srt[0]), float(srt[-1])],
+                                                    dtype=torch.float64, device=srt.device),
+                   srt[:995] + 1e-7])
+    qp, qc = rk.query(x.contiguous())
+    cnt = torch.searchsorted(srt, x, right=True)
+    assert torch.equal(qc, cnt)
+    want = torch.where(cnt > 0, pos[(cnt - 1).clamp(min=0)], torch.zeros_like(x))
+    assert torch.equal(qp.view(torch.int64), want.view(torch.int64))
+    # against the C oracle's sequential prefix sum on a subsample of 2e5 keys
+    sub = keys[:200000].contiguous()
+    rs = DeviceRank(sub)
+    osrt, opos = c_oracle.rank_build(sub.cpu().numpy())
+    assert np.array_equal(rs.keys_sorted.cpu().numpy().view(np.uint64), osrt.view(np.uint64))
+    assert np.all(np.abs(rs.positions.cpu().numpy() - opos) <= REL * opos)
+
+
+def test_rank_edge_sizes():
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for n in (1, 2, 63, 64, 65, 4095, 4096, 4097, 100001):
+        keys = (torch.rand(n, generator=g, dtype=torch.float64) * 60).to(dev)
+        if n > 10:
+            keys[n // 2:] = keys[: n - n // 2]          # duplicates
+        rk = DeviceRank(keys)
+        srt, _ = torch.sort(keys)
+        assert torch.equal(rk.keys_sorted.view(torch.int64), srt.view(torch.int64)), n
+        ref = torch.cumsum(torch.exp2(srt - np.log2(n)), 0)
+        assert float(((rk.positions - ref).abs() / ref).max()) < REL, n
+    same = torch.full((5000,), 12.5, dtype=torch.float64, device=dev)      # every radix pass trivial
+    rk = DeviceRank(same)
+    assert torch.equal(rk.keys_sorted, same)
+    # a shard weights with the GLOBAL n (multi-GPU decomposition)
+    keys = (torch.rand(5000, generator=g, dtype=torch.float64) * 40).to(dev)
+    full = DeviceRank(keys)
+    a, b = DeviceRank(keys[:2000].contiguous(), n_global=5000), DeviceRank(keys[2000:].contiguous(), n_global=5000)
+    x = torch.linspace(0, 45, 777, dtype=torch.float64, device=dev)
+    pf, cf = full.query(x)
+    pa, ca = a.query(x)
+    pb, cb = b.query(x)
+    assert torch.equal(cf, ca + cb)
+    assert float(((pa + pb - pf).abs() / pf.clamp(min=1e-300)).max()) < REL
+
+
+def test_distribution_vs_reference_sampler(train_char):
+    """(d): the reference's own Mersenne-Twister samples (golden/dist_backwords_thr10.npz) against
+    Philox samples from the GPU: two-sample KS on -log2 p, chi-square on string length."""
+    from scipy import stats
+    ref = np.load(golden_path("dist_backwords_thr10.npz"))
+    m = BackWordsMonteCarlo(synth.as_file(train_char), splitter="", threshold=10)
+    res = m._dev.sample(200000, 2024, want_len=True)
+    m._dev.check()
+    ks = stats.ks_2samp(res["ml2p"].cpu().numpy(), ref["ml2p"])
+    assert ks.pvalue > 1e-3, ks
+    lens = res["len"].cpu().numpy()
+    top = int(max(lens.max(), ref["len"].max())) + 1
+    a, b = np.bincount(lens, minlength=top).astype(float), np.bincount(ref["len"], minlength=top).astype(float)
+    keep = (a + b) >= 50
+    table = np.vstack([a[keep], b[keep]])
+    chi = stats.chi2_contingency(table)
+    assert chi[1] > 1e-3, chi[:2]
+
+
+def golden_path(name):
+    import os
+    from conftest import GOLDEN
+    return os.path.join(GOLDEN, name)

@@ -123,3 +123,60 @@ def test_pick_clamps_at_total():
     # reference raises IndexError when u == cum[-1] (ProbLib.py:41-42); the build clamps.
     row = orc.expand_row({"a": 0.5, "b": 0.75})          # total 1.25 > 1
     assert orc.pick(row, lambda: 1.0)[1] == "b"
+
+
+# ------------------------------------------------------------------ C restatement (oracle/mc_oracle.c)
+def _c_model(kind, table, **kw):
+    from oracle import c_oracle
+    return c_oracle.COracleModel(table, kind, **kw)
+
+
+def _check_c(fx, cm, drop, n_scores=True):
+    items = fx["samples"]["items"]
+    res = cm.sample(len(items), fx["samples"]["seed"], stride=300)
+    got = [[hx(a), s, int(d)] for a, s, d in zip(res["ml2p"], cm.strings(res, drop=drop), res["draws"])]
+    assert got == items
+    if n_scores and "scores" in fx:
+        pw = [s[0] for s in fx["scores"]]
+        assert [hx(x) for x in cm.score(pw)] == [s[1] for s in fx["scores"]]
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_c_oracle_nwords(train_char, n):
+    from oracle import c_oracle
+    probs, words = orc.train_nwords(train_char, n, "", "\x03")
+    cm = _c_model(c_oracle.KIND_NGRAM, orc.expand_table(probs), order=n - 1, start_units=["\x00"] * (n - 1))
+    _check_c(golden(f"nwords_n{n}_char.json"), cm, "\x00")
+
+
+@pytest.mark.parametrize("thr", [2, 10])
+def test_c_oracle_backwords(train_char, thr):
+    from oracle import c_oracle
+    probs, words = orc.train_backwords(train_char, "", "\x00", "\x03", 0, 1, thr, 256)
+    cm = _c_model(c_oracle.KIND_BACKOFF, orc.expand_table(probs), start_units=["\x00"])
+    _check_c(golden(f"backwords_thr{thr}_char.json"), cm, "\x00")
+
+
+def test_c_oracle_subword_and_v2(train_tab, train_v2):
+    from oracle import c_oracle
+    probs, _ = orc.train_backwords(train_tab, "\t", "\x00", "\x03", 0, 1, 3, 256)
+    cm = _c_model(c_oracle.KIND_BACKOFF, orc.expand_table(probs), start_units=["\x00"])
+    _check_c(golden("backwords_thr3_tab.json"), cm, "\x00", n_scores=False)
+    probs, _ = orc.train_v2(train_v2, 4)
+    cm = _c_model(c_oracle.KIND_V2, orc.expand_table(probs), order=3, start_units=[], flags=1)
+    _check_c(golden("v2_n4.json"), cm, "")
+
+
+def test_c_oracle_rank():
+    from oracle import c_oracle
+    import numpy as np
+    fx = golden("rank.json")
+    keys = np.array([fh(x) for x in fx["draw_order"]])
+    srt, pos = c_oracle.rank_build(keys)
+    assert [hx(x) for x in srt] == fx["sorted"]
+    want = np.array([fh(x) for x in fx["positions"]])
+    assert np.allclose(pos, want, rtol=1e-12, atol=0)       # libm pow vs numpy power: not bit-pinned
+    x = np.array([fh(p[0]) for p in fx["probes"]])
+    qp, qc = c_oracle.rank_query(srt, want, x)
+    for (xx, w), p, c in zip(fx["probes"], qp, qc):
+        assert hx(p if c > 0 else 1) == w

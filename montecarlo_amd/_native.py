@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch bundles its own libamdhip64.so (SONAME libamdhip64.so.7).  It must be in the process BEFORE
+# libmi355mc.so is loaded, so that the loader resolves our DT_NEEDED libamdhip64.so.7 to that same
+# copy: two HIP runtimes in one process leave the second without a device.
+import torch  # noqa: F401  (device memory, streams and torch.distributed are torch's anyway)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355mc.so")
 

@@ -248,13 +248,18 @@ __global__ void __launch_bounds__(SORT_THREADS) k_scatter(const Plan *__restrict
 }
 
 // ---- positions: prefix sum of 2^(key - log2 n_global) ------------------------------------------
-__device__ __forceinline__ double block_inclusive_scan(double v, double *wave_tot, double &block_total) {
+// Exclusive prefix of `v` over the workgroup (and the workgroup total).  The exclusive value is
+// shuffled, never formed as inclusive - v: the weights span 2^-20..2^90, and that subtraction
+// cancels catastrophically when one lane's value dwarfs everything before it.
+__device__ __forceinline__ double block_exclusive_scan(double v, double *wave_tot, double &block_total) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     double inc = v;
     for (int o = 1; o < 64; o <<= 1) {
         double u = __shfl_up(inc, o);
         if (lane >= o) inc += u;
     }
+    double excl = __shfl_up(inc, 1);
+    if (lane == 0) excl = 0.0;
     __syncthreads();  // protect wave_tot from the previous use
     if (lane == 63) wave_tot[wid] = inc;
     __syncthreads();
@@ -265,7 +270,7 @@ __device__ __forceinline__ double block_inclusive_scan(double v, double *wave_to
         tot += t;
     }
     block_total = tot;
-    return off + inc;
+    return off + excl;
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS) k_weight_sums(const double *__restrict__ keys, u64 n, u64 chunk,
@@ -275,7 +280,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_weight_sums(const double *__re
     double s = 0.0;
     for (u64 i = lo + threadIdx.x; i < hi; i += SCAN_THREADS) s += exp2(keys[i] - logn);
     double tot;
-    (void)block_inclusive_scan(s, wave_tot, tot);
+    (void)block_exclusive_scan(s, wave_tot, tot);
     if (threadIdx.x == 0) partials[blockIdx.x] = tot;
 }
 
@@ -287,7 +292,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_partials(double *partials
     double s = 0.0;
     for (u32 i = lo; i < hi; ++i) s += partials[i];
     double tot;
-    double run = block_inclusive_scan(s, wave_tot, tot) - s;
+    double run = block_exclusive_scan(s, wave_tot, tot);
     for (u32 i = lo; i < hi; ++i) {
         const double v = partials[i];
         partials[i] = run;  // exclusive
@@ -313,7 +318,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_positions(const double *__rest
             w[j] = s;  // inclusive within the lane
         }
         double tot;
-        const double excl = block_inclusive_scan(s, wave_tot, tot) - s;
+        const double excl = block_exclusive_scan(s, wave_tot, tot);
 #pragma unroll
         for (int j = 0; j < SCAN_ITEMS; ++j)
             if (i0 + j < hi) pos[i0 + j] = carry + (excl + w[j]);

@@ -214,7 +214,7 @@ def test_rank_edge_sizes():
     for n in (1, 2, 63, 64, 65, 4095, 4096, 4097, 100001):
         keys = (torch.rand(n, generator=g, dtype=torch.float64) * 60).to(dev)
         if n > 10:
-            keys[n // 2:] = keys[: n - n // 2]          # duplicates
+            keys[n // 2:] = keys[: n - n // 2].clone()          # duplicates
         rk = DeviceRank(keys)
         srt, _ = torch.sort(keys)
         assert torch.equal(rk.keys_sorted.view(torch.int64), srt.view(torch.int64)), n

@@ -35,7 +35,7 @@ typedef unsigned int u32;
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_ITEMS = 16;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 4096 keys per tile
-constexpr int SORT_MAX_BLOCKS = 2048;
+constexpr int SORT_MAX_BLOCKS = 1024;  // = 256 lanes x 4 counters: one row of counts per scan workgroup
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
@@ -128,37 +128,39 @@ __global__ void __launch_bounds__(SORT_THREADS) k_count(const Plan *__restrict__
     counts[(u64)threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
 }
 
-// exclusive scan of counts[256*nblocks] in place, one workgroup of 1024 lanes
-__global__ void __launch_bounds__(1024) k_scan_counts(const Plan *__restrict__ plan, int pass, u32 *counts, u32 len) {
+// counts[d][b] -> global write offset of digit d for workgroup b.  One workgroup per digit: the
+// digit's start is the sum of the smaller digits' totals (known from the upfront histograms, which
+// are permutation-invariant), the row of per-workgroup counts is scanned in one coalesced sweep.
+__global__ void __launch_bounds__(256) k_scan_counts(const Plan *__restrict__ plan, int pass, u32 *counts, u32 nb,
+                                                     const u32 *__restrict__ hist) {
     if (plan->skip[pass]) return;
-    __shared__ u32 wave_tot[16];
-    const u32 per = (len + 1023) / 1024;
-    const u32 lo = min(len, threadIdx.x * per), hi = min(len, lo + per);
-    u32 sum = 0;
-    for (u32 i = lo; i < hi; ++i) sum += counts[i];
-    // block-wide exclusive scan of `sum`
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __shared__ u32 wave_a[4], wave_b[4];
+    const u32 d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    u32 below = tid < d ? hist[pass * 256 + tid] : 0;
+    for (int o = 32; o > 0; o >>= 1) below += __shfl_down(below, o);
+    u32 *row = counts + (u64)d * nb;
+    u32 c[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u32 i = tid * 4 + j;
+        c[j] = i < nb ? row[i] : 0;
+        sum += c[j];
+    }
     u32 inc = sum;
     for (int o = 1; o < 64; o <<= 1) {
         u32 v = __shfl_up(inc, o);
         if (lane >= o) inc += v;
     }
-    if (lane == 63) wave_tot[wid] = inc;
+    if (lane == 0) wave_a[wid] = below;
+    if (lane == 63) wave_b[wid] = inc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        u32 c = 0;
-        for (int w = 0; w < 16; ++w) {
-            u32 v = wave_tot[w];
-            wave_tot[w] = c;
-            c += v;
-        }
-    }
-    __syncthreads();
-    u32 run = wave_tot[wid] + inc - sum;
-    for (u32 i = lo; i < hi; ++i) {
-        u32 v = counts[i];
-        counts[i] = run;
-        run += v;
+    u32 run = wave_a[0] + wave_a[1] + wave_a[2] + wave_a[3] + inc - sum;
+    for (u32 w = 0; w < wid; ++w) run += wave_b[w];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u32 i = tid * 4 + j;
+        if (i < nb) row[i] = run;
+        run += c[j];
     }
 }
 
@@ -406,7 +408,7 @@ extern "C" int mc_rank_build(const double *keys_in, uint64_t n, uint64_t n_globa
     for (int pass = 0; pass < 8; ++pass) {
         hipLaunchKernelGGL(k_count, dim3(nb), dim3(SORT_THREADS), 0, s, ws.plan, pass, in, (const u64 *)A,
                            (const u64 *)B, (u64)n, chunk, ws.counts);
-        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, ws.plan, pass, ws.counts, 256u * nb);
+        hipLaunchKernelGGL(k_scan_counts, dim3(256), dim3(256), 0, s, ws.plan, pass, ws.counts, nb, (const u32 *)ws.hist);
         hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(SORT_THREADS), 0, s, ws.plan, pass, in, A, B, (u64)n, chunk,
                            ws.counts);
     }

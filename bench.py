@@ -30,6 +30,7 @@ from montecarlo_amd import synth  # noqa: E402
 from montecarlo_amd.backwords_simulator import BackWordsMonteCarlo  # noqa: E402
 from montecarlo_amd.engine import DeviceRank  # noqa: E402
 from montecarlo_amd import _native as nv  # noqa: E402
+from montecarlo_amd import dist as mcd  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 # algorithmic bytes of one draw in k_sample (DESIGN.md "Sampling kernel"): state record 32 B,
@@ -91,9 +92,7 @@ def main():
         dm.score_device(d_syms, d_off, T, out=t_ml2p)
         marks[3].record()
         rk.query(t_ml2p, out_pos=q_pos, out_cnt=q_cnt)
-        if world > 1:
-            dist.all_reduce(q_pos)
-            dist.all_reduce(q_cnt)
+        mcd.combine_partials(q_pos, q_cnt)                  # one RCCL all-reduce each; no-op on one GPU
         marks[4].record()
         if timed:
             ev["sample"].append((marks[0], marks[1]))

@@ -1,0 +1,56 @@
+"""Multi-GPU decomposition of the guess-number estimate.
+
+positions[idx-1] = sum over samples j with ml2p_j <= x of 2^(ml2p_j - log2 N)
+(reference lib4mc/MonteCarloLib.py:24-32) is a sum over samples, so it splits over
+disjoint sample shards as long as every shard weights with the GLOBAL N.  Each
+rank draws its own sample ids on the shared Philox stream, sorts and scans
+locally and answers every test password locally; ONE all-reduce (SUM) of the
+fp64 partial sums (and of the int64 counts, which decide the reference's
+``idx > 0`` branch) finishes the estimate.  Samples never move between GPUs.
+
+Backend: torch.distributed -- "nccl" is RCCL over xGMI on the GPU box, "gloo" in
+the CPU tests.  T <= 1e6 test passwords is 8 MB: latency-bound, one bucket.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_global: int, rank: int, world: int) -> Tuple[int, int]:
+    """Sample ids [first, first+count) of ``rank``: contiguous, sizes differ by at most one."""
+    base, extra = divmod(n_global, world)
+    count = base + (1 if rank < extra else 0)
+    first = rank * base + min(rank, extra)
+    return first, count
+
+
+def combine_partials(pos: torch.Tensor, cnt: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Sum the per-shard (partial position, count) vectors in place over the group."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(pos, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+    return pos, cnt
+
+
+def estimates(pos: torch.Tensor, cnt: torch.Tensor) -> torch.Tensor:
+    """The reference's ``positions[idx-1] if idx > 0 else 1`` on combined vectors."""
+    return torch.where(cnt > 0, pos, torch.ones_like(pos))
+
+
+def sharded_guess_numbers(model, n_global: int, seed: int, test_ml2p: torch.Tensor, group=None,
+                          first_id: int = 0):
+    """One rank's part of: sample n_global strings over the group, build the local rank
+    index, query the (replicated) test keys, all-reduce.  Returns (estimates, cnt, DeviceRank)."""
+    from .engine import DeviceRank
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    first, count = shard_range(n_global, rank, world)
+    keys = model._dev.sample(count, seed, first_id=first_id + first, max_draws=model.max_draws)["ml2p"]
+    rk = DeviceRank(keys, n_global=n_global)
+    pos, cnt = rk.query(test_ml2p)
+    combine_partials(pos, cnt, group)
+    model._dev.check()
+    return estimates(pos, cnt), cnt, rk

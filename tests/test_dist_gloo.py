@@ -1,0 +1,72 @@
+"""The N>1 path on CPU: two gloo ranks each hold one shard of the samples (drawn and
+ranked by the C oracle, since there is no GPU here), the PRODUCT's sharding and
+combination code (montecarlo_amd/dist.py) merges the per-shard partial sums, and the
+result must equal the single-shard estimate of the whole sample set (1e-9 relative)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, golden_lines
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_global, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from montecarlo_amd import dist as mcd
+    from oracle import c_oracle, mc_oracle as orc
+    probs, _ = orc.train_backwords(golden_lines("train_char.txt"), "", "\x00", "\x03", 0, 1, 10, 256)
+    cm = c_oracle.COracleModel(orc.expand_table(probs), c_oracle.KIND_BACKOFF, start_units=["\x00"])
+    first, count = mcd.shard_range(n_global, rank, world)
+    keys = cm.sample(count, 77, first_id=first)["ml2p"]
+    srt, pos = c_oracle.rank_build(keys, n_global=n_global)
+    x = np.linspace(0.0, 60.0, 501)
+    p, c = c_oracle.rank_query(srt, pos, x)
+    tp, tc = torch.from_numpy(p.copy()), torch.from_numpy(c.astype(np.int64))
+    mcd.combine_partials(tp, tc)
+    est = mcd.estimates(tp, tc)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "est.npy"), est.numpy())
+        np.save(os.path.join(out_dir, "cnt.npy"), tc.numpy())
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions():
+    from montecarlo_amd.dist import shard_range
+    for n, w in ((10, 3), (7, 8), (10_000_000_000, 8), (0, 2)):
+        parts = [shard_range(n, r, w) for r in range(w)]
+        assert parts[0][0] == 0 and sum(c for _, c in parts) == n
+        for (f0, c0), (f1, _) in zip(parts, parts[1:]):
+            assert f0 + c0 == f1
+        assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_matches_single_shard(tmp_path):
+    n_global, world = 5001, 2
+    mp.spawn(_worker, args=(world, _free_port(), n_global, str(tmp_path)), nprocs=world, join=True)
+    est = np.load(tmp_path / "est.npy")
+    cnt = np.load(tmp_path / "cnt.npy")
+    from oracle import c_oracle, mc_oracle as orc
+    probs, _ = orc.train_backwords(golden_lines("train_char.txt"), "", "\x00", "\x03", 0, 1, 10, 256)
+    cm = c_oracle.COracleModel(orc.expand_table(probs), c_oracle.KIND_BACKOFF, start_units=["\x00"])
+    keys = cm.sample(n_global, 77)["ml2p"]
+    srt, pos = c_oracle.rank_build(keys)
+    p, c = c_oracle.rank_query(srt, pos, np.linspace(0.0, 60.0, 501))
+    want = np.where(c > 0, p, 1.0)
+    assert np.array_equal(cnt, c.astype(np.int64))
+    assert cnt[0] == 0 and est[0] == 1.0                       # below every sample: the reference's `1`
+    assert np.all(np.abs(est - want) <= 1e-9 * want)

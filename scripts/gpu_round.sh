@@ -1,0 +1,53 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): GPU tests, bench, rocprofv3 kernel trace and the two
+# HBM-traffic counter passes.  Usage: scripts/gpu_round.sh <tag> [tests|bench|prof|pmc ...]
+# Every GPU step has its own time limit and the script stops at the first failure.
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${1:-run}
+shift || true
+STEPS=${*:-tests bench prof pmc}
+OUT=$R/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd "$R" || exit 1
+
+die() { echo "FAILED: $1 (rc=$2)"; exit "$2"; }
+
+for s in $STEPS; do
+  case $s in
+    tests)
+      timeout -k 10 600 python3 -u -m pytest tests -m gpu -x -q --timeout 180 --timeout-method thread \
+        > "$OUT/gpu_tests.log" 2>&1 || { rc=$?; tail -30 "$OUT/gpu_tests.log"; die tests $rc; }
+      tail -3 "$OUT/gpu_tests.log" ;;
+    bench)
+      timeout -k 10 400 python3 bench.py --steps 10 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err" \
+        || { rc=$?; tail -20 "$OUT/bench.err"; die bench $rc; }
+      cat "$OUT/bench.json" ;;
+    prof)
+      timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o r -- \
+        python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_prof.json" 2> "$OUT/prof.err" \
+        || { rc=$?; tail -20 "$OUT/prof.err"; die prof $rc; }
+      find "$OUT/trace" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats.csv" \;
+      rm -f $(find "$OUT/trace" -name '*kernel_trace.csv')   # large; the stats are what we keep
+      head -8 "$OUT/kernel_stats.csv" | cut -c1-160 ;;
+    pmc)
+      for c in FETCH_SIZE WRITE_SIZE; do
+        timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_$c" -o r -- \
+          python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_$c.json" 2> "$OUT/pmc_$c.err" \
+          || { rc=$?; tail -20 "$OUT/pmc_$c.err"; die pmc_$c $rc; }
+      done
+      python3 scripts/pmc_summary.py "$OUT" > "$OUT/pmc_summary.json" && cat "$OUT/pmc_summary.json" ;;
+    pmcx)   # free-form counter passes: PMCX="SQ_WAVES SQ_INSTS_VALU;TCP_..." (one rocprofv3 run per ';' group)
+      i=0
+      IFS=';' read -ra GROUPS_ <<< "${PMCX:-SQ_WAVES}"
+      for grp in "${GROUPS_[@]}"; do
+        i=$((i+1))
+        timeout -s KILL 240 rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmcx_$i" -o r -- \
+          python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmcx_$i.json" 2> "$OUT/pmcx_$i.err" \
+          || { rc=$?; tail -20 "$OUT/pmcx_$i.err"; die pmcx_$i $rc; }
+      done
+      python3 scripts/pmcx_summary.py "$OUT" | tee "$OUT/pmcx_summary.txt" ;;
+  esac
+done
+echo "gpu_round $TAG done"

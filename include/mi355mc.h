@@ -80,7 +80,7 @@ typedef struct mc_model_desc {
     uint32_t min_len;       /* accept a sample iff pwd_len >= min_len (nwords_simulator.py:101; v2 `> 3`) */
     uint32_t max_len;       /* restart when pwd_len >= max_len (nwords_simulator.py:112): 256 */
     uint32_t flags;         /* MC_FLAG_* */
-    uint32_t guide_factor;  /* guide buckets per row ~ guide_factor * row length, rounded up to 2^k (0 -> 2) */
+    uint32_t guide_factor;  /* draw-table buckets per row ~ guide_factor * row length, rounded up to 2^k (0 -> 2) */
 } mc_model_desc;
 
 typedef struct mc_table mc_table; /* compiled table, host memory */
@@ -93,8 +93,8 @@ const char *mc_last_error(void);
  * Replaces the per-call dict/tuple work of `_get_prefix` (nwords_simulator.py:30-34,
  * backwords_simulator.py:28-41) and `pick_expand`'s bisect (lib4mc/ProbLib.py:31-43) by
  * precomputed arrays: per-entry next-state links, per-row parent (backoff) links, an exact
- * guide table for the inverse-CDF draw, an open-addressed (row,symbol)->entry hash and an
- * open-addressed 64-bit context-hash -> row index.
+ * bucketed draw table for the inverse-CDF draw (see mc_draw_rec), an open-addressed
+ * (row,symbol)->entry hash and an open-addressed 64-bit context-hash -> row index.
  */
 int mc_table_compile(const mc_model_desc *desc, mc_table **out);
 void mc_table_free(mc_table *t);
@@ -103,12 +103,14 @@ void mc_table_free(mc_table *t);
  * flat arrays.  `what` names the array; returns its byte size, copies at most `cap` bytes. */
 enum {
     MC_ARR_STATE = 0,    /* mc_state_rec[n_ctx] */
-    MC_ARR_GUIDE = 1,    /* uint32[] */
-    MC_ARR_CUM = 2,      /* double[n_ent] */
-    MC_ARR_PAYLOAD = 3,  /* mc_payload[n_ent] */
+    MC_ARR_DRAW = 1,     /* mc_draw_rec[]: per row 2^gbits buckets over the uniform */
+    MC_ARR_CUM = 2,      /* double[n_ent]: the reference's cumsum (host only; the device uses RCUM) */
+    MC_ARR_PAYLOAD = 3,  /* mc_payload[n_ent] (scoring) */
     MC_ARR_TRANS = 4,    /* mc_slot[trans_cap]: key = row<<32|sym, val = entry */
     MC_ARR_CTXHASH = 5,  /* mc_slot[ctx_cap]: key = 64-bit context hash, val = row */
-    MC_ARR_SYMCHARS = 6  /* uint32[n_sym] */
+    MC_ARR_SYMCHARS = 6, /* uint32[n_sym] */
+    MC_ARR_SPAY = 7,     /* mc_draw_rec[n_ent]: MC_DRAW_DIRECT record of every entry (sampling) */
+    MC_ARR_RCUM = 8      /* double[n_ent]: per-entry thresholds in the uniform's domain (see mc_draw_rec) */
 };
 int64_t mc_table_array(const mc_table *t, int what, void *dst, size_t cap);
 /* start state, end symbol, root (zero-gram) row, table sizes ... as 16 uint64 (see mc_table_info_idx) */
@@ -116,7 +118,8 @@ int mc_table_info(const mc_table *t, uint64_t info[16]);
 enum {
     MC_INFO_NCTX = 0, MC_INFO_NENT = 1, MC_INFO_NSYM = 2, MC_INFO_START_STATE = 3, MC_INFO_ROOT = 4,
     MC_INFO_TRANS_CAP = 5, MC_INFO_CTX_CAP = 6, MC_INFO_GUIDE_LEN = 7, MC_INFO_DEVICE_BYTES = 8,
-    MC_INFO_MAX_ROW = 9, MC_INFO_KIND = 10, MC_INFO_MULTICHAR = 11
+    MC_INFO_MAX_ROW = 9, MC_INFO_KIND = 10, MC_INFO_MULTICHAR = 11, MC_INFO_START_DRAW = 12,
+    MC_INFO_DIRECT_BUCKETS = 13, MC_INFO_ONE_BUCKETS = 14, MC_INFO_MULTI_BUCKETS = 15
 };
 /* 64-bit hash of a context (sequence of unit ids) as stored in the context index. */
 uint64_t mc_ctx_hash(const uint32_t *units, uint32_t n);
@@ -126,8 +129,8 @@ typedef struct mc_state_rec {
     double total;       /* cum[last] of the row: random.uniform(0, total), ProbLib.py:40-41 */
     uint32_t ent_off;   /* first entry of the row */
     uint32_t len;       /* entries in the row */
-    uint32_t guide_off; /* first guide word of the row */
-    uint32_t gbits;     /* log2(guide buckets) */
+    uint32_t guide_off; /* first draw-table bucket (mc_draw_rec index) of the row */
+    uint32_t gbits;     /* log2(buckets of the row) */
     uint32_t parent;    /* longest proper suffix that is a row (BACKOFF), else MC_NONE */
     uint32_t ctx_len;   /* context length in units */
 } mc_state_rec;
@@ -137,6 +140,34 @@ typedef struct mc_payload {
     uint32_t next;      /* state after taking the entry (MC_NONE: no such row) */
     uint32_t sym;       /* transition symbol id; bit 31 set on the end symbol */
 } mc_payload;
+
+/*
+ * Draw table: the reference draws idx = bisect_right(cum, total * r) with r = random.random()
+ * (lib4mc/ProbLib.py:40-42).  fl(total * r) is monotone in r, so for every entry j of a row
+ * there is a smallest double T_j in [0,1] with fl(total * T_j) >= cum[j]; then
+ *     idx = #{ j < len-1 : r >= T_j }                        (same index, bit for bit)
+ * and the device never multiplies: RCUM[j] = T_j (the row's last entry holds 2.0: the reference's
+ * IndexError at u == cum[-1] is clamped to the last entry).  A row owns 2^gbits buckets; bucket
+ * k = floor(r * 2^gbits) is ONE 16-byte record telling what r in [k, k+1) / 2^gbits lands on:
+ *   MC_DRAW_DIRECT  every such r lands on one entry: the record IS that entry's sampling
+ *                   payload {ml2p, next, meta};
+ *   MC_DRAW_ONE     one threshold inside the bucket: {T, lo}; idx = lo + (r >= T);
+ *   MC_DRAW_MULTI   cnt >= 2 thresholds: {cnt, -, lo}; idx = lo + bisect_right(RCUM[lo..lo+cnt), r).
+ * For ONE / MULTI the entry's record is then read from SPAY[idx].
+ * meta (word 3): bit 31 end symbol, bits 30-29 record type, bits 28-24 gbits of the NEXT row,
+ * bits 23-0 symbol id; `next` (word 2) = first bucket of the NEXT row (MC_NONE: no such row),
+ * so a draw needs nothing but its own record to continue.
+ */
+enum { MC_DRAW_DIRECT = 0, MC_DRAW_ONE = 1, MC_DRAW_MULTI = 2 };
+#define MC_DRAW_END 0x80000000u
+#define MC_DRAW_TYPE(meta) (((meta) >> 29) & 3u)
+#define MC_DRAW_GBITS(meta) (((meta) >> 24) & 31u)
+#define MC_DRAW_SYM(meta) ((meta) & 0x00FFFFFFu)
+#define MC_MAX_SYMBOLS 0x01000000u /* symbol ids must fit the 24-bit field */
+
+typedef struct mc_draw_rec {
+    uint32_t w[4];      /* DIRECT: f64 ml2p | next | meta;  ONE: f64 T | lo | meta;  MULTI: cnt | 0 | lo | meta */
+} mc_draw_rec;
 
 typedef struct mc_slot {
     uint64_t key;       /* ~0 = empty */
@@ -150,7 +181,8 @@ int mc_model_upload(const mc_table *t, int device, mc_model **out);
 void mc_model_destroy(mc_model *m);
 /* Synchronises `stream`, reads and clears the model's device status words.  Returns
  * MC_ERR_DIVERGED if any sample since the last check exhausted its draws.  counters (may be
- * NULL) receives {draws, cdf_probes, restarts, failed_samples, score_probes, ...} (8 words). */
+ * NULL) receives {draws, threshold compares, restarts, failed samples, score probes, score steps,
+ * indirect draws (bucket not DIRECT), -} (8 words). */
 int mc_model_check(mc_model *m, void *stream, uint64_t counters[8]);
 
 /* ---- sampling: MonteCarlo.sample, lib4mc/MonteCarloParent.py:33-46, whose loop body is

@@ -19,9 +19,11 @@ LIB_PATH = os.path.join(_HERE, "libmi355mc.so")
 MC_NONE = 0xFFFFFFFF
 KIND_NGRAM, KIND_BACKOFF, KIND_V2 = 1, 2, 3
 FLAG_KEEP_LEN_ON_RESTART = 1
-(ARR_STATE, ARR_GUIDE, ARR_CUM, ARR_PAYLOAD, ARR_TRANS, ARR_CTXHASH, ARR_SYMCHARS) = range(7)
+(ARR_STATE, ARR_DRAW, ARR_CUM, ARR_PAYLOAD, ARR_TRANS, ARR_CTXHASH, ARR_SYMCHARS, ARR_SPAY, ARR_RCUM) = range(9)
 (INFO_NCTX, INFO_NENT, INFO_NSYM, INFO_START_STATE, INFO_ROOT, INFO_TRANS_CAP, INFO_CTX_CAP, INFO_GUIDE_LEN,
- INFO_DEVICE_BYTES, INFO_MAX_ROW, INFO_KIND, INFO_MULTICHAR) = range(12)
+ INFO_DEVICE_BYTES, INFO_MAX_ROW, INFO_KIND, INFO_MULTICHAR, INFO_START_DRAW, INFO_DIRECT_BUCKETS,
+ INFO_ONE_BUCKETS, INFO_MULTI_BUCKETS) = range(16)
+DRAW_DIRECT, DRAW_ONE, DRAW_MULTI = 0, 1, 2
 ERR_DIVERGED = -5
 
 u32p = C.POINTER(C.c_uint32)

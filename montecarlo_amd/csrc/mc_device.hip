@@ -4,8 +4,8 @@
 // lib4mc/MonteCarloParent.py:33-46, nwords_simulator.py:92-116, lib4mc/ProbLib.py:31-43):
 // one lane per sampled string, persistent: a lane that finishes a string immediately
 // claims the next sample id of its workgroup from an LDS cursor, so lanes never wait for
-// the longest string of their wave.  Every step of a lane is one draw:
-//   state record (32 B) -> guide bucket (8 B) -> [0..few cum probes] -> payload (16 B).
+// the longest string of their wave.  Every step of a lane is one draw = one 16-byte record
+// of the bucketed draw table (buckets that straddle a threshold: + threshold(s) + 16 B).
 // The accumulation `prob += -log2 p` is done in fp64 in draw order, so ml2p is
 // bit-identical to the reference for the same uniforms.
 //
@@ -49,8 +49,9 @@ static_assert(sizeof(Slot) == sizeof(mc_slot) && sizeof(Slot) == 16, "slot layou
 
 struct DevModel {
     const StateRec *state;
-    const uint32_t *guide;
-    const double *cum;
+    const mc_draw_rec *draw;
+    const mc_draw_rec *spay;
+    const double *rcum;
     const Payload *payload;
     const Slot *trans;
     const Slot *ctxhash;
@@ -58,6 +59,7 @@ struct DevModel {
     unsigned long long *status;
     unsigned long long trans_mask, ctx_mask;
     uint32_t start_state, root, end_sym, min_len, max_len, flags, n_ctx, n_sym;
+    uint32_t start_draw, start_gbits;
 };
 
 struct SampleArgs {
@@ -75,8 +77,9 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
                                                uint32_t k1, uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t hi0 = __umulhi(PH_M0, c0), lo0 = PH_M0 * c0;
-        uint32_t hi1 = __umulhi(PH_M1, c2), lo1 = PH_M1 * c2;
+        const unsigned long long p0 = (unsigned long long)PH_M0 * c0, p1 = (unsigned long long)PH_M1 * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0;
         c1 = lo1;
@@ -91,110 +94,147 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     o3 = c3;
 }
 
+struct alignas(16) DrawRec {
+    uint32_t w0, w1, w2, w3;
+};
+static_assert(sizeof(DrawRec) == sizeof(mc_draw_rec), "draw record layout");
+
+__device__ __forceinline__ double rec_f64(const DrawRec &q) {
+    return __longlong_as_double((long long)(((unsigned long long)q.w1 << 32) | q.w0));
+}
+
+// One lane = one sampled string at a time.  A loop iteration produces one Philox block (two
+// 53-bit uniforms: draws 2j and 2j+1 of the lane's sample) in uniform control flow and then takes
+// up to two draws; a lane whose string ends on the first of them idles for the second (its next
+// string starts with a Philox block of its own).  A draw reads ONE 16-byte record of the draw
+// table (mc_draw_rec, include/mi355mc.h); only buckets that straddle a threshold read more.
 template <bool INJECT, bool MULTICHAR>
 __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
     __shared__ unsigned int cursor;
-    __shared__ unsigned int blk_cnt[4];
+    __shared__ unsigned int blk_cnt[5];
     const unsigned long long per = (a.count + gridDim.x - 1) / gridDim.x;
     const unsigned long long b0 = min(a.count, (unsigned long long)blockIdx.x * per);
     const unsigned long long b1 = min(a.count, b0 + per);
     const unsigned int nblk = (unsigned int)(b1 - b0);
     if (threadIdx.x == 0) cursor = 0;
-    if (threadIdx.x < 4) blk_cnt[threadIdx.x] = 0;
+    if (threadIdx.x < 5) blk_cnt[threadIdx.x] = 0;
     __syncthreads();
 
-    unsigned int c_draws = 0, c_probes = 0, c_restart = 0, c_fail = 0;
+    unsigned int c_draws = 0, c_probes = 0, c_restart = 0, c_fail = 0, c_indirect = 0;
     unsigned int local = atomicAdd(&cursor, 1u);
     bool active = local < nblk;
 
-    uint32_t state = m.start_state, plen = 0, nsym = 0, draw = 0;
-    uint32_t w2 = 0, w3 = 0;
+    uint32_t goff = m.start_draw, gbits = m.start_gbits, plen = 0, nsym = 0, draw = 0;
     double acc = 0.0;
     const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
     const bool keep_len = (m.flags & MC_FLAG_KEEP_LEN_ON_RESTART) != 0;
+    const DrawRec *__restrict__ dtab = (const DrawRec *)m.draw;
+    const DrawRec *__restrict__ spay = (const DrawRec *)m.spay;
 
     while (active) {
         const unsigned long long i = b0 + local;
-        // ---- uniform -------------------------------------------------------------------
-        double r;
-        unsigned long long m53 = 0;
+        // ---- two uniforms (draw is even here) ---------------------------------------------
+        unsigned long long m53[2] = {0, 0};
+        double rr[2] = {0.0, 0.0};
         if (INJECT) {
-            r = a.uniforms[i * a.max_draws + draw];
+            const double *u = a.uniforms + i * a.max_draws + draw;
+            rr[0] = u[0];
+            rr[1] = draw + 1 < a.max_draws ? u[1] : 0.0;
         } else {
-            uint32_t wa, wb;
-            if ((draw & 1u) == 0) {
-                const unsigned long long sid = a.first_id + i;
-                philox4x32_10((uint32_t)sid, (uint32_t)(sid >> 32), draw >> 1, 0u, k0, k1, wa, wb, w2, w3);
+            const unsigned long long sid = a.first_id + i;
+            uint32_t o0, o1, o2, o3;
+            philox4x32_10((uint32_t)sid, (uint32_t)(sid >> 32), draw >> 1, 0u, k0, k1, o0, o1, o2, o3);
+            m53[0] = ((unsigned long long)(o0 >> 5) << 26) | (unsigned long long)(o1 >> 6);
+            m53[1] = ((unsigned long long)(o2 >> 5) << 26) | (unsigned long long)(o3 >> 6);
+        }
+        bool fresh = false;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (fresh) continue;
+            // ---- inverse CDF: same index as bisect_right(cum, total * r) -------------------
+            uint32_t k;
+            if (INJECT) {
+                const double kk = rr[h] * (double)(1u << gbits);
+                const uint32_t kmax = (1u << gbits) - 1u;
+                k = kk >= (double)kmax ? kmax : (kk > 0.0 ? (uint32_t)kk : 0u);
             } else {
-                wa = w2;
-                wb = w3;
+                k = (uint32_t)(m53[h] >> (53u - gbits));
             }
-            m53 = ((unsigned long long)(wa >> 5) << 26) | (unsigned long long)(wb >> 6);
-            r = (double)m53 * 0x1.0p-53;
+            DrawRec q = dtab[goff + k];
+            const uint32_t type = MC_DRAW_TYPE(q.w3);
+            if (type != MC_DRAW_DIRECT) {
+                const double r = INJECT ? rr[h] : (double)m53[h] * 0x1.0p-53;
+                uint32_t idx = q.w2;
+                if (type == MC_DRAW_ONE) {
+                    idx += (r >= rec_f64(q)) ? 1u : 0u;
+                    ++c_probes;
+                } else {
+                    uint32_t lo = 0, hi = q.w0;
+                    const double *T = m.rcum + q.w2;
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (T[mid] > r) hi = mid; else lo = mid + 1;
+                        ++c_probes;
+                    }
+                    idx += lo;
+                }
+                q = spay[idx];
+                ++c_indirect;
+            }
+            acc += rec_f64(q);
+            ++draw;
+            ++c_draws;
+            // ---- sample1's control flow (nwords_simulator.py:100-115) ------------------------
+            bool done = false, ok = false, restart = false;
+            if (q.w3 & MC_DRAW_END) {
+                if (plen >= m.min_len) done = ok = true; else restart = true;
+            } else {
+                const uint32_t s = MC_DRAW_SYM(q.w3);
+                if (a.out_syms && nsym < a.sym_stride) a.out_syms[i * a.sym_stride + nsym] = s;
+                ++nsym;
+                plen += MULTICHAR ? m.sym_chars[s] : 1u;
+                goff = q.w2;
+                gbits = MC_DRAW_GBITS(q.w3);
+                if (plen >= m.max_len) restart = true;
+            }
+            if (restart) {
+                goff = m.start_draw;
+                gbits = m.start_gbits;
+                acc = 0.0;
+                nsym = 0;
+                if (!keep_len) plen = 0;
+                ++c_restart;
+            }
+            if (!done && (draw >= a.max_draws || goff == MC_NONE)) {
+                done = true;  // ok stays false: the reference would loop on / crash here
+                ++c_fail;
+            }
+            if (done) {
+                a.out_ml2p[i] = ok ? acc : __longlong_as_double(0x7FF8000000000000ll);
+                if (a.out_len) a.out_len[i] = nsym;
+                if (a.out_draws) a.out_draws[i] = draw;
+                fresh = true;
+                goff = m.start_draw;
+                gbits = m.start_gbits;
+                acc = 0.0;
+                plen = nsym = draw = 0;
+            }
         }
-        // ---- inverse CDF: same index as bisect_right(cum, total * r) ---------------------
-        const StateRec rec = m.state[state];
-        uint32_t k;
-        if (INJECT) {
-            const double kk = r * (double)(1u << rec.gbits);
-            const uint32_t kmax = (1u << rec.gbits) - 1u;
-            k = kk >= (double)kmax ? kmax : (kk > 0.0 ? (uint32_t)kk : 0u);
-        } else {
-            k = (uint32_t)(m53 >> (53u - rec.gbits));
-        }
-        const uint32_t *g = m.guide + rec.guide_off + k;
-        uint32_t lo = g[0], hi = g[1];
-        const double x = rec.total * r;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (m.cum[mid] > x) hi = mid; else lo = mid + 1;
-            ++c_probes;
-        }
-        const Payload p = m.payload[lo];
-        acc += p.ml2p;
-        ++draw;
-        ++c_draws;
-        // ---- sample1's control flow (nwords_simulator.py:100-115) ------------------------
-        bool done = false, ok = false, restart = false;
-        if (p.sym & 0x80000000u) {
-            if (plen >= m.min_len) done = ok = true; else restart = true;
-        } else {
-            const uint32_t s = p.sym;
-            if (a.out_syms && nsym < a.sym_stride) a.out_syms[i * a.sym_stride + nsym] = s;
-            ++nsym;
-            plen += MULTICHAR ? m.sym_chars[s] : 1u;
-            state = p.next;
-            if (plen >= m.max_len) restart = true;
-        }
-        if (restart) {
-            state = m.start_state;
-            acc = 0.0;
-            nsym = 0;
-            if (!keep_len) plen = 0;
-            ++c_restart;
-        }
-        if (!done && (draw >= a.max_draws || state == MC_NONE)) {
-            done = true;  // ok stays false: the reference would loop on / crash here
-            ++c_fail;
-        }
-        if (done) {
-            a.out_ml2p[i] = ok ? acc : __longlong_as_double(0x7FF8000000000000ll);
-            if (a.out_len) a.out_len[i] = nsym;
-            if (a.out_draws) a.out_draws[i] = draw;
+        if (fresh) {
             local = atomicAdd(&cursor, 1u);
             active = local < nblk;
-            state = m.start_state;
-            acc = 0.0;
-            plen = nsym = draw = 0;
         }
     }
     atomicAdd(&blk_cnt[0], c_draws);
     atomicAdd(&blk_cnt[1], c_probes);
     atomicAdd(&blk_cnt[2], c_restart);
     atomicAdd(&blk_cnt[3], c_fail);
+    atomicAdd(&blk_cnt[4], c_indirect);
     __syncthreads();
-    if (threadIdx.x < 4 && blk_cnt[threadIdx.x])
-        atomicAdd(&m.status[MC_CNT_DRAWS + threadIdx.x], (unsigned long long)blk_cnt[threadIdx.x]);
+    if (threadIdx.x < 5 && blk_cnt[threadIdx.x]) {
+        const int word = threadIdx.x < 4 ? MC_CNT_DRAWS + threadIdx.x : MC_CNT_INDIRECT;
+        atomicAdd(&m.status[word], (unsigned long long)blk_cnt[threadIdx.x]);
+    }
 }
 
 __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
@@ -302,8 +342,9 @@ extern "C" int mc_model_upload(const mc_table *t, int device, mc_model **out) {
     };
     DevModel &d = m->dev;
     d.state = (const StateRec *)put(t->state.data(), t->state.size() * sizeof(mc_state_rec));
-    d.guide = (const uint32_t *)put(t->guide.data(), t->guide.size() * sizeof(uint32_t));
-    d.cum = (const double *)put(t->cum.data(), t->cum.size() * sizeof(double));
+    d.draw = (const mc_draw_rec *)put(t->draw.data(), t->draw.size() * sizeof(mc_draw_rec));
+    d.spay = (const mc_draw_rec *)put(t->spay.data(), t->spay.size() * sizeof(mc_draw_rec));
+    d.rcum = (const double *)put(t->rcum.data(), t->rcum.size() * sizeof(double));
     d.payload = (const Payload *)put(t->payload.data(), t->payload.size() * sizeof(mc_payload));
     d.trans = (const Slot *)put(t->trans.data(), t->trans.size() * sizeof(mc_slot));
     d.ctxhash = (const Slot *)put(t->ctxhash.data(), t->ctxhash.size() * sizeof(mc_slot));
@@ -322,6 +363,8 @@ extern "C" int mc_model_upload(const mc_table *t, int device, mc_model **out) {
     d.flags = t->flags;
     d.n_ctx = t->n_ctx;
     d.n_sym = t->n_sym;
+    d.start_draw = t->start_draw;
+    d.start_gbits = t->start_gbits;
     HIP_TRY(hipSetDevice(prev));
     *out = m;
     return MC_OK;

@@ -13,7 +13,8 @@ enum {
     MC_CNT_RESTARTS = 2,   // samples restarted (too short / too long)
     MC_CNT_FAILED = 3,     // samples that hit max_draws or a missing row
     MC_CNT_SCORE_PROBES = 4,  // transition-hash slots read while scoring
-    MC_CNT_SCORE_STEPS = 5    // symbols consumed while scoring
+    MC_CNT_SCORE_STEPS = 5,   // symbols consumed while scoring
+    MC_CNT_INDIRECT = 6       // draws whose bucket was not DIRECT (one more 16-byte record read)
 };
 
 struct mc_table {
@@ -23,7 +24,11 @@ struct mc_table {
     uint32_t start_state, root, max_row;
     bool multichar;
     std::vector<mc_state_rec> state;
-    std::vector<uint32_t> guide;
+    std::vector<mc_draw_rec> draw;   // bucketed draw table (all rows)
+    std::vector<mc_draw_rec> spay;   // per-entry DIRECT records
+    std::vector<double> rcum;        // per-entry thresholds T_j
+    uint32_t start_draw, start_gbits;
+    uint64_t n_direct, n_one, n_multi;
     std::vector<double> cum;
     std::vector<mc_payload> payload;
     std::vector<mc_slot> trans;

@@ -6,10 +6,11 @@
 // cumulative sums (lib4mc/ProbLib.py:40-41).  On the GPU both are replaced by data:
 //   * next[e]   : the row that applies after taking entry e (one u32 per entry);
 //   * parent[r] : the next shorter row that is a suffix of row r's context (backoff);
-//   * guide     : per row, 2^gbits buckets over the uniform; bucket k stores the first
-//                 and last entry the draw can land on, so the exact fp64 comparison
-//                 `cum[i] > total*r` is only evaluated inside that (usually one-entry)
-//                 range.  The result is the same index bisect_right returns.
+//   * draw      : per row, 2^gbits buckets over the uniform r; a bucket is one 16-byte record
+//                 that either IS the entry every r of the bucket lands on (ml2p, next row's
+//                 buckets, symbol) or brackets the few candidates, which are then told apart
+//                 by thresholds precomputed in r's own domain (include/mi355mc.h, mc_draw_rec).
+//                 The result is the index bisect_right(cum, total*r) returns, bit for bit.
 //   * trans     : open-addressed (row,symbol) -> entry hash for scoring;
 //   * ctxhash   : open-addressed 64-bit context hash -> row index (by-context lookups).
 // Host-only code: no HIP here, so it is testable in a container without a GPU.
@@ -56,6 +57,24 @@ uint64_t pow2ceil(uint64_t v) {
     uint64_t p = 1;
     while (p < v) p <<= 1;
     return p;
+}
+
+// Smallest double r in [0, 1] with fl(total * r) >= c (c <= total).  fl(total * r) is monotone
+// in r and non-negative doubles order like their bit patterns, so bisect on the bits.
+double draw_threshold(double total, double c) {
+    uint64_t lo = 0, hi;
+    const double one = 1.0;
+    std::memcpy(&hi, &one, sizeof hi);
+    while (lo < hi) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        double r;
+        std::memcpy(&r, &mid, sizeof r);
+        volatile double prod = total * r;  // one rounding to double, as the reference's total * random()
+        if (prod >= c) hi = mid; else lo = mid + 1;
+    }
+    double r;
+    std::memcpy(&r, &lo, sizeof r);
+    return r;
 }
 
 struct CtxIndex {
@@ -208,13 +227,19 @@ extern "C" int mc_table_compile(const mc_model_desc *d, mc_table **out) {
         }
     }
 
-    // ---- state records, guide tables, payloads -------------------------------------------
+    // ---- state records, payloads with next-state links ---------------------------------------
+    if (d->n_sym > MC_MAX_SYMBOLS) {
+        mc_set_error("%u symbols: the draw records hold 24-bit symbol ids (at most %u)", d->n_sym, MC_MAX_SYMBOLS);
+        delete t;
+        return MC_ERR_TABLE;
+    }
     uint32_t gf = d->guide_factor ? d->guide_factor : 2;
     t->state.resize(d->n_ctx);
     t->cum.assign(d->ent_cum, d->ent_cum + d->n_ent);
     t->payload.resize(d->n_ent);
     t->max_row = 0;
     std::vector<uint32_t> seq;
+    uint64_t n_buckets = 0;
     for (uint32_t r = 0; r < d->n_ctx; ++r) {
         const uint64_t e0 = d->row_off[r], e1 = d->row_off[r + 1];
         const uint32_t L = (uint32_t)(e1 - e0);
@@ -233,8 +258,8 @@ extern "C" int mc_table_compile(const mc_model_desc *d, mc_table **out) {
                 delete t;
                 return MC_ERR_TABLE;
             }
-        if (!(st.total > 0.0)) {
-            mc_set_error("row %u: total probability mass is not positive", r);
+        if (!(st.total > 0.0) || !(st.total < 1e300)) {
+            mc_set_error("row %u: total probability mass is not a positive finite number", r);
             delete t;
             return MC_ERR_TABLE;
         }
@@ -247,8 +272,6 @@ extern "C" int mc_table_compile(const mc_model_desc *d, mc_table **out) {
                 }
             }
         }
-        // guide: K = 2^gbits buckets over r in [0,1); bucket k can only land on entries
-        // [upper_bound(cum, total*k/K), upper_bound(cum, total*(k+1)/K)] (clamped to L-1).
         uint32_t gbits = 0;
         if (L > 1) {
             uint64_t K = pow2ceil((uint64_t)gf * L);
@@ -256,22 +279,13 @@ extern "C" int mc_table_compile(const mc_model_desc *d, mc_table **out) {
             if (gbits > 16) gbits = 16;
         }
         st.gbits = gbits;
-        st.guide_off = (uint32_t)t->guide.size();
-        const uint32_t K = 1u << gbits;
-        for (uint32_t k = 0; k < K; ++k) {
-            double frac = (double)k / (double)K;  // exact
-            double y = st.total * frac;           // one rounding, like total*r on the device
-            uint32_t lo = (uint32_t)(std::upper_bound(cum, cum + L, y) - cum);
-            if (lo > L - 1) lo = L - 1;
-            t->guide.push_back((uint32_t)e0 + lo);
-        }
-        t->guide.push_back((uint32_t)e0 + L - 1);
-        if (t->guide.size() >= 0xFFFFFFF0ull) {
-            mc_set_error("guide table exceeds 2^32 words; lower guide_factor");
+        st.guide_off = (uint32_t)n_buckets;
+        n_buckets += 1ull << gbits;
+        if (n_buckets >= 0xFFFFFFF0ull) {
+            mc_set_error("draw table exceeds 2^32 buckets; lower guide_factor");
             delete t;
             return MC_ERR_TABLE;
         }
-        // payloads with next-state links
         for (uint64_t e = e0; e < e1; ++e) {
             uint32_t s = d->ent_sym[e];
             seq.assign(d->ctx_units + ca, d->ctx_units + ca + cn);
@@ -284,6 +298,61 @@ extern "C" int mc_table_compile(const mc_model_desc *d, mc_table **out) {
             p.ml2p = d->ent_ml2p[e];
             p.next = state_of(seq.data(), (uint32_t)seq.size());
             p.sym = s | (s == d->end_sym ? 0x80000000u : 0u);
+        }
+    }
+    if (t->start_state != MC_NONE) {
+        t->start_draw = t->state[t->start_state].guide_off;
+        t->start_gbits = t->state[t->start_state].gbits;
+    } else {
+        t->start_draw = MC_NONE;
+        t->start_gbits = 0;
+    }
+
+    // ---- draw table: thresholds in the uniform's domain, per-entry records, buckets ----------
+    t->rcum.resize(d->n_ent);
+    t->spay.resize(d->n_ent);
+    t->draw.resize(n_buckets);
+    t->n_direct = t->n_one = t->n_multi = 0;
+    for (uint32_t r = 0; r < d->n_ctx; ++r) {
+        const mc_state_rec &st = t->state[r];
+        const uint64_t e0 = st.ent_off;
+        const uint32_t L = st.len;
+        double *T = t->rcum.data() + e0;
+        for (uint32_t j = 0; j + 1 < L; ++j) T[j] = draw_threshold(st.total, t->cum[e0 + j]);
+        T[L - 1] = 2.0;  // never reached: u == cum[-1] is clamped to the last entry
+        for (uint32_t j = 0; j < L; ++j) {
+            const mc_payload &p = t->payload[e0 + j];
+            mc_draw_rec &q = t->spay[e0 + j];
+            std::memcpy(&q.w[0], &p.ml2p, sizeof(double));
+            uint32_t nb = 0;
+            q.w[2] = MC_NONE;
+            if (p.next != MC_NONE) {
+                q.w[2] = t->state[p.next].guide_off;
+                nb = t->state[p.next].gbits;
+            }
+            q.w[3] = (p.sym & MC_DRAW_END) | ((uint32_t)MC_DRAW_DIRECT << 29) | (nb << 24) | (p.sym & 0x00FFFFFFu);
+        }
+        const uint32_t K = 1u << st.gbits;
+        for (uint32_t k = 0; k < K; ++k) {
+            const double a = (double)k / (double)K, b = (double)(k + 1) / (double)K;  // exact
+            const uint32_t lo = (uint32_t)(std::upper_bound(T, T + (L - 1), a) - T);
+            const uint32_t hi = (uint32_t)(std::lower_bound(T, T + (L - 1), b) - T);
+            mc_draw_rec &q = t->draw[(uint64_t)st.guide_off + k];
+            if (hi <= lo) {
+                q = t->spay[e0 + lo];
+                ++t->n_direct;
+            } else if (hi == lo + 1) {
+                std::memcpy(&q.w[0], &T[lo], sizeof(double));
+                q.w[2] = (uint32_t)(e0 + lo);
+                q.w[3] = (uint32_t)MC_DRAW_ONE << 29;
+                ++t->n_one;
+            } else {
+                q.w[0] = hi - lo;
+                q.w[1] = 0;
+                q.w[2] = (uint32_t)(e0 + lo);
+                q.w[3] = (uint32_t)MC_DRAW_MULTI << 29;
+                ++t->n_multi;
+            }
         }
     }
 
@@ -318,7 +387,9 @@ extern "C" int64_t mc_table_array(const mc_table *t, int what, void *dst, size_t
     size_t bytes = 0;
     switch (what) {
         case MC_ARR_STATE: src = t->state.data(); bytes = t->state.size() * sizeof(mc_state_rec); break;
-        case MC_ARR_GUIDE: src = t->guide.data(); bytes = t->guide.size() * sizeof(uint32_t); break;
+        case MC_ARR_DRAW: src = t->draw.data(); bytes = t->draw.size() * sizeof(mc_draw_rec); break;
+        case MC_ARR_SPAY: src = t->spay.data(); bytes = t->spay.size() * sizeof(mc_draw_rec); break;
+        case MC_ARR_RCUM: src = t->rcum.data(); bytes = t->rcum.size() * sizeof(double); break;
         case MC_ARR_CUM: src = t->cum.data(); bytes = t->cum.size() * sizeof(double); break;
         case MC_ARR_PAYLOAD: src = t->payload.data(); bytes = t->payload.size() * sizeof(mc_payload); break;
         case MC_ARR_TRANS: src = t->trans.data(); bytes = t->trans.size() * sizeof(mc_slot); break;
@@ -340,19 +411,24 @@ extern "C" int mc_table_info(const mc_table *t, uint64_t info[16]) {
     info[MC_INFO_ROOT] = t->root;
     info[MC_INFO_TRANS_CAP] = t->trans.size();
     info[MC_INFO_CTX_CAP] = t->ctxhash.size();
-    info[MC_INFO_GUIDE_LEN] = t->guide.size();
+    info[MC_INFO_GUIDE_LEN] = t->draw.size();
     info[MC_INFO_DEVICE_BYTES] = mc_table_device_bytes(t);
     info[MC_INFO_MAX_ROW] = t->max_row;
     info[MC_INFO_KIND] = t->kind;
     info[MC_INFO_MULTICHAR] = t->multichar ? 1 : 0;
+    info[MC_INFO_START_DRAW] = t->start_draw | ((uint64_t)t->start_gbits << 32);
+    info[MC_INFO_DIRECT_BUCKETS] = t->n_direct;
+    info[MC_INFO_ONE_BUCKETS] = t->n_one;
+    info[MC_INFO_MULTI_BUCKETS] = t->n_multi;
     return MC_OK;
 }
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 size_t mc_table_device_bytes(const mc_table *t) {
-    return align256(t->state.size() * sizeof(mc_state_rec)) + align256(t->guide.size() * sizeof(uint32_t)) +
-           align256(t->cum.size() * sizeof(double)) + align256(t->payload.size() * sizeof(mc_payload)) +
+    return align256(t->state.size() * sizeof(mc_state_rec)) + align256(t->draw.size() * sizeof(mc_draw_rec)) +
+           align256(t->spay.size() * sizeof(mc_draw_rec)) + align256(t->rcum.size() * sizeof(double)) +
+           align256(t->payload.size() * sizeof(mc_payload)) +
            align256(t->trans.size() * sizeof(mc_slot)) + align256(t->ctxhash.size() * sizeof(mc_slot)) +
            align256(t->sym_chars.size() * sizeof(uint32_t)) + align256(MC_STATUS_WORDS * sizeof(uint64_t));
 }

@@ -16,7 +16,7 @@ from . import _native as nv
 from .tables import FlatTable
 
 DEFAULT_MAX_DRAWS = 1 << 16
-CNT_NAMES = ("draws", "cdf_probes", "restarts", "failed", "score_probes", "score_steps", "_6", "_7")
+CNT_NAMES = ("draws", "cdf_probes", "restarts", "failed", "score_probes", "score_steps", "indirect_draws", "_7")
 
 
 def _require_gpu():

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, Iterable, List, Optional, Sequence
 
 import numpy as np
@@ -22,6 +23,7 @@ STATE_DT = np.dtype([("total", "<f8"), ("ent_off", "<u4"), ("len", "<u4"), ("gui
                      ("parent", "<u4"), ("ctx_len", "<u4")])
 PAYLOAD_DT = np.dtype([("ml2p", "<f8"), ("next", "<u4"), ("sym", "<u4")])
 SLOT_DT = np.dtype([("key", "<u8"), ("val", "<u4"), ("pad", "<u4")])
+DRAW_DT = np.dtype([("w", "<u4", (4,))])
 
 
 def _ptr(arr: np.ndarray, typ):
@@ -33,7 +35,9 @@ class FlatTable:
 
     def __init__(self, expanded: Dict, kind: int, *, order: int = 0, start_units: Sequence[str] = (),
                  end_chr: str = "\x03", min_len: int = 4, max_len: int = 256, flags: int = 0,
-                 minus_log_based: bool = False, unit_of_symbol=None, guide_factor: int = 2):
+                 minus_log_based: bool = False, unit_of_symbol=None, guide_factor: Optional[int] = None):
+        if guide_factor is None:
+            guide_factor = int(os.environ.get("MC_GUIDE_FACTOR", "2"))
         self.kind = kind
         sym_id: Dict[str, int] = {}
         symbols: List[str] = []
@@ -132,9 +136,9 @@ class FlatTable:
 
     # ---- introspection (tests, DESIGN.md byte accounting) -------------------------------
     def array(self, what: int) -> np.ndarray:
-        dt = {nv.ARR_STATE: STATE_DT, nv.ARR_GUIDE: np.dtype("<u4"), nv.ARR_CUM: np.dtype("<f8"),
+        dt = {nv.ARR_STATE: STATE_DT, nv.ARR_DRAW: DRAW_DT, nv.ARR_CUM: np.dtype("<f8"),
               nv.ARR_PAYLOAD: PAYLOAD_DT, nv.ARR_TRANS: SLOT_DT, nv.ARR_CTXHASH: SLOT_DT,
-              nv.ARR_SYMCHARS: np.dtype("<u4")}[what]
+              nv.ARR_SYMCHARS: np.dtype("<u4"), nv.ARR_SPAY: DRAW_DT, nv.ARR_RCUM: np.dtype("<f8")}[what]
         size = nv.check(nv.lib.mc_table_array(self._h, what, None, 0))
         out = np.empty(size // dt.itemsize, dtype=dt)
         nv.check(nv.lib.mc_table_array(self._h, what, out.ctypes.data_as(C.c_void_p), size))

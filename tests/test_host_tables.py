@@ -123,21 +123,34 @@ def test_v2(train_v2):
     check_walk(fx, m, keep_len=True)
 
 
-def test_guide_brackets_bisect(train_char):
-    """Every guide bucket [lo, hi] contains bisect_right(cum, total*r) for r at the
-    bucket's edges and just inside them (the exactness argument of mc_table.cpp)."""
+def test_draw_table_equals_bisect(train_char):
+    """The bucketed draw table returns bisect_right(cum, total*r) (clamped to the last entry, the
+    reference raises there) for r at every bucket's edges, just inside them, at every threshold
+    and its two neighbours, and at random r -- and every DIRECT record equals its entry's."""
     m = BackWordsMonteCarlo(synth.as_file(train_char), splitter="", threshold=10)
     w = CompiledWalker(m._flat)
     rng = np.random.default_rng(5)
+    kinds = set()
     for r_ in rng.choice(len(w.state), size=300, replace=False):
         rec = w.state[r_]
-        e0, L, K = int(rec["ent_off"]), int(rec["len"]), 1 << int(rec["gbits"])
+        e0, L, g = int(rec["ent_off"]), int(rec["len"]), int(rec["gbits"])
+        K, goff, total = 1 << g, int(rec["guide_off"]), float(rec["total"])
         cum = w.cum[e0:e0 + L]
+        probes = []
         for k in range(K):
-            lo, hi = int(w.guide[int(rec["guide_off"]) + k]) - e0, int(w.guide[int(rec["guide_off"]) + k + 1]) - e0
-            for r in (k / K, np.nextafter((k + 1) / K, 0.0), (k + 0.5) / K):
-                idx = min(int(np.searchsorted(cum, float(rec["total"]) * r, side="right")), L - 1)
-                assert lo <= idx <= hi
+            probes += [k / K, np.nextafter((k + 1) / K, 0.0), (k + 0.5) / K]
+            kinds.add((int(w.draw[goff + k][3]) >> 29) & 3)
+        for t in w.rcum[e0:e0 + L - 1]:
+            probes += [float(t), float(np.nextafter(t, 0.0)), float(np.nextafter(t, 2.0))]
+        probes += rng.random(50).tolist()
+        for r in probes:
+            if not 0.0 <= r < 1.0:
+                continue
+            want = min(int(np.searchsorted(cum, total * r, side="right")), L - 1)
+            q, idx = w.lookup(goff, g, r)
+            assert np.array_equal(q, w.spay[e0 + want]), (r_, r)
+            assert idx is None or idx == e0 + want
+    assert kinds == {nv.DRAW_DIRECT, nv.DRAW_ONE, nv.DRAW_MULTI}
 
 
 def test_compile_rejects_bad_tables():

@@ -23,50 +23,69 @@ class CompiledWalker:
     def __init__(self, flat):
         self.flat = flat
         self.state = flat.array(nv.ARR_STATE)
-        self.guide = flat.array(nv.ARR_GUIDE)
+        self.draw = flat.array(nv.ARR_DRAW)["w"]
+        self.spay = flat.array(nv.ARR_SPAY)["w"]
+        self.rcum = flat.array(nv.ARR_RCUM)
         self.cum = flat.array(nv.ARR_CUM)
         self.payload = flat.array(nv.ARR_PAYLOAD)
         self.trans = flat.array(nv.ARR_TRANS)
         self.sym_chars = flat.array(nv.ARR_SYMCHARS)
         self.start = flat.info[nv.INFO_START_STATE]
+        self.start_draw = flat.info[nv.INFO_START_DRAW] & 0xFFFFFFFF
+        self.start_gbits = flat.info[nv.INFO_START_DRAW] >> 32
+
+    @staticmethod
+    def f64(q):
+        return float(np.array([q[0], q[1]], dtype="<u4").view("<f8")[0])
+
+    # the entry's DIRECT record for uniform r drawn in the row whose buckets start at goff
+    def lookup(self, goff, gbits, r):
+        K = 1 << gbits
+        k = min(int(r * K), K - 1)
+        q = self.draw[goff + k]
+        typ = (int(q[3]) >> 29) & 3
+        if typ != nv.DRAW_DIRECT:
+            idx = int(q[2])
+            if typ == nv.DRAW_ONE:
+                idx += 1 if r >= self.f64(q) else 0
+            else:
+                lo, hi = 0, int(q[0])
+                while lo < hi:
+                    mid = (lo + hi) >> 1
+                    if self.rcum[int(q[2]) + mid] > r:
+                        hi = mid
+                    else:
+                        lo = mid + 1
+                idx += lo
+            return self.spay[idx], idx
+        return q, None
 
     # mirrors k_sample: returns (ml2p, symbol ids, draws)
     def sample(self, uniform, min_len=4, max_len=256, keep_len=False, max_draws=1 << 16):
-        st, acc, plen, syms, draw = self.start, 0.0, 0, [], 0
+        goff, gbits, acc, plen, syms, draw = self.start_draw, self.start_gbits, 0.0, 0, [], 0
         while True:
             r = uniform()
-            rec = self.state[st]
-            K = 1 << int(rec["gbits"])
-            k = min(int(r * K), K - 1)
-            lo = int(self.guide[int(rec["guide_off"]) + k])
-            hi = int(self.guide[int(rec["guide_off"]) + k + 1])
-            x = float(rec["total"]) * r
-            while lo < hi:
-                mid = (lo + hi) >> 1
-                if self.cum[mid] > x:
-                    hi = mid
-                else:
-                    lo = mid + 1
-            p = self.payload[lo]
-            acc += float(p["ml2p"])
+            q, _ = self.lookup(goff, gbits, r)
+            acc += self.f64(q)
             draw += 1
             restart = False
-            if int(p["sym"]) & 0x80000000:
+            meta = int(q[3])
+            if meta & 0x80000000:
                 if plen >= min_len:
                     return acc, syms, draw
                 restart = True
             else:
-                s = int(p["sym"])
+                s = meta & 0xFFFFFF
                 syms.append(s)
                 plen += int(self.sym_chars[s])
-                st = int(p["next"])
+                goff, gbits = int(q[2]), (meta >> 24) & 31
                 if plen >= max_len:
                     restart = True
             if restart:
-                st, acc, syms = self.start, 0.0, []
+                goff, gbits, acc, syms = self.start_draw, self.start_gbits, 0.0, []
                 if not keep_len:
                     plen = 0
-            if draw >= max_draws or st == NONE:
+            if draw >= max_draws or goff == NONE:
                 return float("nan"), syms, draw
 
     def find(self, row, s):

@@ -80,7 +80,7 @@ typedef struct mc_model_desc {
     uint32_t min_len;       /* accept a sample iff pwd_len >= min_len (nwords_simulator.py:101; v2 `> 3`) */
     uint32_t max_len;       /* restart when pwd_len >= max_len (nwords_simulator.py:112): 256 */
     uint32_t flags;         /* MC_FLAG_* */
-    uint32_t guide_factor;  /* draw-table buckets per row ~ guide_factor * row length, rounded up to 2^k (0 -> 2) */
+    uint32_t guide_factor;  /* draw-table buckets per row ~ guide_factor * row length, rounded up to 2^k (0 -> 4) */
 } mc_model_desc;
 
 typedef struct mc_table mc_table; /* compiled table, host memory */

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -103,12 +104,14 @@ __device__ __forceinline__ double rec_f64(const DrawRec &q) {
     return __longlong_as_double((long long)(((unsigned long long)q.w1 << 32) | q.w0));
 }
 
-// One lane = one sampled string at a time.  A loop iteration produces one Philox block (two
-// 53-bit uniforms: draws 2j and 2j+1 of the lane's sample) in uniform control flow and then takes
-// up to two draws; a lane whose string ends on the first of them idles for the second (its next
-// string starts with a Philox block of its own).  A draw reads ONE 16-byte record of the draw
-// table (mc_draw_rec, include/mi355mc.h); only buckets that straddle a threshold read more.
-template <bool INJECT, bool MULTICHAR>
+// One lane walks NC sampled strings at a time (independent chains: their table reads are in
+// flight together).  A loop iteration produces, per chain, one Philox block (two 53-bit uniforms:
+// draws 2j and 2j+1 of that chain's sample) in uniform control flow and then takes up to two draws
+// per chain; a chain whose string ends on the first draw idles for the second (its next string
+// starts with a Philox block of its own).  A draw reads ONE 16-byte record of the draw table
+// (mc_draw_rec, include/mi355mc.h); only buckets that straddle a threshold read more.  Finished
+// strings are written at the end of the iteration, so no load waits behind a store.
+template <bool INJECT, bool MULTICHAR, int NC>
 __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
     __shared__ unsigned int cursor;
     __shared__ unsigned int blk_cnt[5];
@@ -121,108 +124,164 @@ __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
     __syncthreads();
 
     unsigned int c_draws = 0, c_probes = 0, c_restart = 0, c_fail = 0, c_indirect = 0;
-    unsigned int local = atomicAdd(&cursor, 1u);
-    bool active = local < nblk;
-
-    uint32_t goff = m.start_draw, gbits = m.start_gbits, plen = 0, nsym = 0, draw = 0;
-    double acc = 0.0;
+    unsigned int local[NC];
+    uint32_t goff[NC], gbits[NC], plen[NC], nsym[NC], draw[NC];
+    double acc[NC];
+    bool live[NC];
+    bool any = false;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        local[c] = atomicAdd(&cursor, 1u);
+        live[c] = local[c] < nblk;
+        any |= live[c];
+        goff[c] = m.start_draw;
+        gbits[c] = m.start_gbits;
+        plen[c] = nsym[c] = draw[c] = 0;
+        acc[c] = 0.0;
+    }
     const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
     const bool keep_len = (m.flags & MC_FLAG_KEEP_LEN_ON_RESTART) != 0;
     const DrawRec *__restrict__ dtab = (const DrawRec *)m.draw;
     const DrawRec *__restrict__ spay = (const DrawRec *)m.spay;
+    const double *__restrict__ rcum = m.rcum;
+    const double nan = __longlong_as_double(0x7FF8000000000000ll);
 
-    while (active) {
-        const unsigned long long i = b0 + local;
-        // ---- two uniforms (draw is even here) ---------------------------------------------
-        unsigned long long m53[2] = {0, 0};
-        double rr[2] = {0.0, 0.0};
-        if (INJECT) {
-            const double *u = a.uniforms + i * a.max_draws + draw;
-            rr[0] = u[0];
-            rr[1] = draw + 1 < a.max_draws ? u[1] : 0.0;
-        } else {
-            const unsigned long long sid = a.first_id + i;
-            uint32_t o0, o1, o2, o3;
-            philox4x32_10((uint32_t)sid, (uint32_t)(sid >> 32), draw >> 1, 0u, k0, k1, o0, o1, o2, o3);
-            m53[0] = ((unsigned long long)(o0 >> 5) << 26) | (unsigned long long)(o1 >> 6);
-            m53[1] = ((unsigned long long)(o2 >> 5) << 26) | (unsigned long long)(o3 >> 6);
+    while (any) {
+        // ---- two uniforms per chain (draw[c] is even here) ---------------------------------
+        unsigned long long m53[NC][2];
+        double rr[NC][2];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const unsigned long long i = b0 + local[c];
+            if (INJECT) {
+                m53[c][0] = m53[c][1] = 0;
+                rr[c][0] = rr[c][1] = 0.0;
+                if (live[c]) {
+                    const double *u = a.uniforms + i * a.max_draws + draw[c];
+                    rr[c][0] = u[0];
+                    if (draw[c] + 1 < a.max_draws) rr[c][1] = u[1];
+                }
+            } else {
+                const unsigned long long sid = a.first_id + i;
+                uint32_t o0, o1, o2, o3;
+                philox4x32_10((uint32_t)sid, (uint32_t)(sid >> 32), draw[c] >> 1, 0u, k0, k1, o0, o1, o2, o3);
+                m53[c][0] = ((unsigned long long)(o0 >> 5) << 26) | (unsigned long long)(o1 >> 6);
+                m53[c][1] = ((unsigned long long)(o2 >> 5) << 26) | (unsigned long long)(o3 >> 6);
+                rr[c][0] = rr[c][1] = 0.0;
+            }
         }
-        bool fresh = false;
+        bool fresh[NC];
+        double res_ml2p[NC];
+        uint32_t res_len[NC], res_draws[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) fresh[c] = false;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            if (fresh) continue;
-            // ---- inverse CDF: same index as bisect_right(cum, total * r) -------------------
-            uint32_t k;
-            if (INJECT) {
-                const double kk = rr[h] * (double)(1u << gbits);
-                const uint32_t kmax = (1u << gbits) - 1u;
-                k = kk >= (double)kmax ? kmax : (kk > 0.0 ? (uint32_t)kk : 0u);
-            } else {
-                k = (uint32_t)(m53[h] >> (53u - gbits));
-            }
-            DrawRec q = dtab[goff + k];
-            const uint32_t type = MC_DRAW_TYPE(q.w3);
-            if (type != MC_DRAW_DIRECT) {
-                const double r = INJECT ? rr[h] : (double)m53[h] * 0x1.0p-53;
-                uint32_t idx = q.w2;
-                if (type == MC_DRAW_ONE) {
-                    idx += (r >= rec_f64(q)) ? 1u : 0u;
-                    ++c_probes;
-                } else {
-                    uint32_t lo = 0, hi = q.w0;
-                    const double *T = m.rcum + q.w2;
-                    while (lo < hi) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if (T[mid] > r) hi = mid; else lo = mid + 1;
-                        ++c_probes;
+            DrawRec q[NC];
+            bool go[NC], ind[NC];
+            uint32_t idx[NC];
+            // ---- phase 1: every chain's bucket record -----------------------------------------
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                go[c] = live[c] && !fresh[c];
+                q[c] = DrawRec{0, 0, 0, 0};
+                if (go[c]) {
+                    uint32_t k;
+                    if (INJECT) {
+                        const double kk = rr[c][h] * (double)(1u << gbits[c]);
+                        const uint32_t kmax = (1u << gbits[c]) - 1u;
+                        k = kk >= (double)kmax ? kmax : (kk > 0.0 ? (uint32_t)kk : 0u);
+                    } else {
+                        k = (uint32_t)(m53[c][h] >> (53u - gbits[c]));
                     }
-                    idx += lo;
+                    q[c] = dtab[goff[c] + k];
                 }
-                q = spay[idx];
-                ++c_indirect;
             }
-            acc += rec_f64(q);
-            ++draw;
-            ++c_draws;
-            // ---- sample1's control flow (nwords_simulator.py:100-115) ------------------------
-            bool done = false, ok = false, restart = false;
-            if (q.w3 & MC_DRAW_END) {
-                if (plen >= m.min_len) done = ok = true; else restart = true;
-            } else {
-                const uint32_t s = MC_DRAW_SYM(q.w3);
-                if (a.out_syms && nsym < a.sym_stride) a.out_syms[i * a.sym_stride + nsym] = s;
-                ++nsym;
-                plen += MULTICHAR ? m.sym_chars[s] : 1u;
-                goff = q.w2;
-                gbits = MC_DRAW_GBITS(q.w3);
-                if (plen >= m.max_len) restart = true;
+            // ---- phase 2: buckets that straddle thresholds: same index as
+            //      bisect_right(cum, total * r), decided in r's own domain ----------------------
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const uint32_t type = MC_DRAW_TYPE(q[c].w3);
+                ind[c] = go[c] && type != MC_DRAW_DIRECT;
+                idx[c] = q[c].w2;
+                if (ind[c]) {
+                    const double r = INJECT ? rr[c][h] : (double)m53[c][h] * 0x1.0p-53;
+                    if (type == MC_DRAW_ONE) {
+                        idx[c] += (r >= rec_f64(q[c])) ? 1u : 0u;
+                        ++c_probes;
+                    } else {
+                        uint32_t lo = 0, hi = q[c].w0;
+                        const double *T = rcum + q[c].w2;
+                        while (lo < hi) {
+                            const uint32_t mid = (lo + hi) >> 1;
+                            if (T[mid] > r) hi = mid; else lo = mid + 1;
+                            ++c_probes;
+                        }
+                        idx[c] += lo;
+                    }
+                    ++c_indirect;
+                }
             }
-            if (restart) {
-                goff = m.start_draw;
-                gbits = m.start_gbits;
-                acc = 0.0;
-                nsym = 0;
-                if (!keep_len) plen = 0;
-                ++c_restart;
-            }
-            if (!done && (draw >= a.max_draws || goff == MC_NONE)) {
-                done = true;  // ok stays false: the reference would loop on / crash here
-                ++c_fail;
-            }
-            if (done) {
-                a.out_ml2p[i] = ok ? acc : __longlong_as_double(0x7FF8000000000000ll);
-                if (a.out_len) a.out_len[i] = nsym;
-                if (a.out_draws) a.out_draws[i] = draw;
-                fresh = true;
-                goff = m.start_draw;
-                gbits = m.start_gbits;
-                acc = 0.0;
-                plen = nsym = draw = 0;
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                if (ind[c]) q[c] = spay[idx[c]];
+            // ---- phase 3: sample1's control flow (nwords_simulator.py:100-115) -----------------
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if (!go[c]) continue;
+                acc[c] += rec_f64(q[c]);
+                ++draw[c];
+                ++c_draws;
+                bool done = false, ok = false, restart = false;
+                if (q[c].w3 & MC_DRAW_END) {
+                    if (plen[c] >= m.min_len) done = ok = true; else restart = true;
+                } else {
+                    const uint32_t s = MC_DRAW_SYM(q[c].w3);
+                    if (a.out_syms && nsym[c] < a.sym_stride)
+                        a.out_syms[(b0 + local[c]) * a.sym_stride + nsym[c]] = s;
+                    ++nsym[c];
+                    plen[c] += MULTICHAR ? m.sym_chars[s] : 1u;
+                    goff[c] = q[c].w2;
+                    gbits[c] = MC_DRAW_GBITS(q[c].w3);
+                    if (plen[c] >= m.max_len) restart = true;
+                }
+                if (restart) {
+                    goff[c] = m.start_draw;
+                    gbits[c] = m.start_gbits;
+                    acc[c] = 0.0;
+                    nsym[c] = 0;
+                    if (!keep_len) plen[c] = 0;
+                    ++c_restart;
+                }
+                if (!done && (draw[c] >= a.max_draws || goff[c] == MC_NONE)) {
+                    done = true;  // ok stays false: the reference would loop on / crash here
+                    ++c_fail;
+                }
+                if (done) {
+                    fresh[c] = true;
+                    res_ml2p[c] = ok ? acc[c] : nan;
+                    res_len[c] = nsym[c];
+                    res_draws[c] = draw[c];
+                    goff[c] = m.start_draw;
+                    gbits[c] = m.start_gbits;
+                    acc[c] = 0.0;
+                    plen[c] = nsym[c] = draw[c] = 0;
+                }
             }
         }
-        if (fresh) {
-            local = atomicAdd(&cursor, 1u);
-            active = local < nblk;
+        // ---- finished strings: write, claim the next id ------------------------------------------
+        any = false;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (fresh[c]) {
+                const unsigned long long i = b0 + local[c];
+                a.out_ml2p[i] = res_ml2p[c];
+                if (a.out_len) a.out_len[i] = res_len[c];
+                if (a.out_draws) a.out_draws[i] = res_draws[c];
+                local[c] = atomicAdd(&cursor, 1u);
+                live[c] = local[c] < nblk;
+            }
+            any |= live[c];
         }
     }
     atomicAdd(&blk_cnt[0], c_draws);
@@ -402,18 +461,29 @@ static int launch_sample(mc_model *m, bool inject, const SampleArgs &a, hipStrea
         mc_set_error("the start context has no row (the reference exits in pick_expand, ProbLib.py:32-36)");
         return MC_ERR_TABLE;
     }
-    // 8 workgroups of 256 lanes per CU keep every SIMD at 8 waves; each workgroup's share must fit u32
-    unsigned long long want = (a.count + 63) / 64;
-    unsigned long long cap = (unsigned long long)m->n_cu * 8;
+    // Workgroups of 256 lanes; 16 per CU, of which 7-8 are resident at a time: a workgroup owns a
+    // contiguous range of sample ids, and the second half of the grid evens out the ranges whose
+    // strings came out long (measured: 16 per CU 12 % faster than 8, 64 slower again).  Two chains
+    // per lane.  Both are tuning knobs (results never depend on them: tests/test_gpu_parity.py).
+    // Each workgroup's share of the sample ids must fit u32.
+    static const int env_nc = getenv("MC_SAMPLE_CHAINS") ? atoi(getenv("MC_SAMPLE_CHAINS")) : 2;
+    static const int env_wg = getenv("MC_SAMPLE_WG_PER_CU") ? atoi(getenv("MC_SAMPLE_WG_PER_CU")) : 16;
+    const int nc = inject ? 1 : env_nc;
+    unsigned long long want = (a.count + 64ull * nc - 1) / (64ull * nc);
+    unsigned long long cap = (unsigned long long)m->n_cu * (env_wg > 0 ? env_wg : 16);
     unsigned long long grid = want < cap ? want : cap;
     while ((a.count + grid - 1) / grid > 0x7FFFFFFFull) grid *= 2;
     dim3 g((unsigned)grid), b(256);
     if (inject) {
-        if (m->multichar) hipLaunchKernelGGL((k_sample<true, true>), g, b, 0, s, m->dev, a);
-        else hipLaunchKernelGGL((k_sample<true, false>), g, b, 0, s, m->dev, a);
+        if (m->multichar) hipLaunchKernelGGL((k_sample<true, true, 1>), g, b, 0, s, m->dev, a);
+        else hipLaunchKernelGGL((k_sample<true, false, 1>), g, b, 0, s, m->dev, a);
+    } else if (m->multichar) {
+        if (nc == 1) hipLaunchKernelGGL((k_sample<false, true, 1>), g, b, 0, s, m->dev, a);
+        else hipLaunchKernelGGL((k_sample<false, true, 2>), g, b, 0, s, m->dev, a);
     } else {
-        if (m->multichar) hipLaunchKernelGGL((k_sample<false, true>), g, b, 0, s, m->dev, a);
-        else hipLaunchKernelGGL((k_sample<false, false>), g, b, 0, s, m->dev, a);
+        if (nc == 1) hipLaunchKernelGGL((k_sample<false, false, 1>), g, b, 0, s, m->dev, a);
+        else if (nc == 4) hipLaunchKernelGGL((k_sample<false, false, 4>), g, b, 0, s, m->dev, a);
+        else hipLaunchKernelGGL((k_sample<false, false, 2>), g, b, 0, s, m->dev, a);
     }
     HIP_TRY(hipGetLastError());
     return MC_OK;

@@ -2,13 +2,16 @@
 // reference lib4mc/MonteCarloLib.py:10-32:
 //     keys.sort(); positions = cumsum(2 ** (keys - log2 n)); bisect_right(keys, x)
 //
-//   sort      LSD radix sort of the fp64 keys as u64 (keys are >= +0.0, so IEEE bit order is
-//             numeric order; NaN = failed sample sorts last), 8-bit digits.  One upfront
-//             kernel builds all 8 digit histograms; passes whose digit is constant over the
-//             whole input (the sign/exponent bytes, typically) are skipped and the ping-pong
-//             is planned so the last pass lands in keys_sorted.  Each pass: per-workgroup
-//             digit counts -> exclusive scan (digit-major) -> stable scatter, the scatter
-//             staged through LDS so global writes are digit-contiguous runs.
+//   sort      onesweep LSD radix sort of the fp64 keys as u64 (keys are >= +0.0, so IEEE bit
+//             order is numeric order; NaN = failed sample sorts last), 8-bit digits.  One
+//             upfront kernel builds all 8 digit histograms; passes whose digit is constant over
+//             the whole input (the sign/exponent bytes, typically) are skipped and the
+//             ping-pong is planned so the last pass lands in keys_sorted.  Each active pass is
+//             ONE kernel that reads every key once and writes it once: a workgroup takes the
+//             next tile (ticket), ranks its 4096 keys by digit (wave ballots), publishes the
+//             tile's digit counts, obtains the counts of all earlier tiles by decoupled
+//             look-back over the published words, and scatters through LDS so global writes
+//             are digit-contiguous runs.
 //   scan      positions = inclusive prefix sum of exp2(key - log2 n_global), fp64,
 //             reduce-then-scan over per-workgroup chunks.
 //   query     one lane per test password: upper_bound over the sorted keys.
@@ -35,7 +38,11 @@ typedef unsigned int u32;
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_ITEMS = 16;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 4096 keys per tile
-constexpr int SORT_MAX_BLOCKS = 1024;  // = 256 lanes x 4 counters: one row of counts per scan workgroup
+// look-back word of (tile, digit): 2 flag bits + count
+constexpr unsigned long long LB_LOCAL = 1ull << 62;  // count of this tile alone
+constexpr unsigned long long LB_INCL = 2ull << 62;   // count of this tile and every earlier one
+constexpr unsigned long long LB_MASK = (1ull << 62) - 1;
+constexpr unsigned int LB_SPIN_LIMIT = 1u << 24;     // a bound, not a protocol: see k_onesweep
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
@@ -46,13 +53,14 @@ struct Plan {
     u32 skip[8];   // pass is a no-op
     u32 src[8];    // 0 = keys_in, 1 = keys_sorted (A), 2 = temp (B)
     u32 dst[8];
+    u32 slot[8];   // look-back region (0/1) the pass uses; it clears the other one for the next pass
     u32 n_active;
 };
 
 struct SortWs {
     u64 *temp;        // [n] second key buffer
-    u32 *hist;        // [8][256]
-    u32 *counts;      // [256][nblocks] digit-major
+    u32 *hist;        // [8][256], then ticket[8], then error flag
+    u64 *lookback;    // [2][tiles][256]
     Plan *plan;
     double *partials; // [scan blocks]
 };
@@ -66,8 +74,21 @@ __global__ void __launch_bounds__(256) k_hist_all(const u64 *__restrict__ keys, 
     __syncthreads();
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
         const u64 k = keys[i];
+        const u64 first = __shfl(k, __ffsll((long long)__ballot(1)) - 1);
+        const u64 diff = k ^ first;
+        const u32 lanes = __popcll(__ballot(1));
+        const bool leader = __popcll(__ballot(1) & ((1ull << (threadIdx.x & 63)) - 1ull)) == 0;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) atomicAdd(&h[p * 256 + digit_of(k, p)], 1u);
+        for (int p = 0; p < 8; ++p) {
+            // a digit the whole wave agrees on (sign/exponent bytes; runs of one repeated password)
+            // costs one LDS add, not 64 colliding ones
+            const bool same = __ballot(((diff >> (8 * p)) & 255ull) != 0) == 0;
+            if (same) {
+                if (leader) atomicAdd(&h[p * 256 + digit_of(k, p)], lanes);
+            } else {
+                atomicAdd(&h[p * 256 + digit_of(k, p)], 1u);
+            }
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 8 * 256; i += blockDim.x)
@@ -89,12 +110,13 @@ __global__ void k_plan(const u32 *__restrict__ hist, u64 n, Plan *plan) {
         u32 cur_src = 0, k = 0;
         for (int p = 0; p < 8; ++p) {
             plan->skip[p] = trivial[p];
-            plan->src[p] = plan->dst[p] = 0;
+            plan->src[p] = plan->dst[p] = plan->slot[p] = 0;
             if (trivial[p]) continue;
             u32 remaining_after = active - k - 1;
             u32 d = (remaining_after % 2 == 0) ? 1 : 2;
             plan->src[p] = cur_src;
             plan->dst[p] = d;
+            plan->slot[p] = k & 1u;
             cur_src = d;
             ++k;
         }
@@ -113,139 +135,133 @@ __global__ void __launch_bounds__(256) k_copy_if_unsorted(const Plan *__restrict
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) out[i] = in[i];
 }
 
-// ---- per pass: digit counts of each workgroup's chunk ----------------------------------------
-__global__ void __launch_bounds__(SORT_THREADS) k_count(const Plan *__restrict__ plan, int pass, const u64 *in,
-                                                         const u64 *a, const u64 *b, u64 n, u64 chunk,
-                                                         u32 *__restrict__ counts) {
-    if (plan->skip[pass]) return;
-    const u64 *src = pick_src(plan->src[pass], in, a, b);
-    __shared__ u32 h[256];
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    const u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
-    for (u64 i = lo + threadIdx.x; i < hi; i += SORT_THREADS) atomicAdd(&h[digit_of(src[i], pass)], 1u);
-    __syncthreads();
-    counts[(u64)threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
-}
-
-// counts[d][b] -> global write offset of digit d for workgroup b.  One workgroup per digit: the
-// digit's start is the sum of the smaller digits' totals (known from the upfront histograms, which
-// are permutation-invariant), the row of per-workgroup counts is scanned in one coalesced sweep.
-__global__ void __launch_bounds__(256) k_scan_counts(const Plan *__restrict__ plan, int pass, u32 *counts, u32 nb,
-                                                     const u32 *__restrict__ hist) {
-    if (plan->skip[pass]) return;
-    __shared__ u32 wave_a[4], wave_b[4];
-    const u32 d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    u32 below = tid < d ? hist[pass * 256 + tid] : 0;
-    for (int o = 32; o > 0; o >>= 1) below += __shfl_down(below, o);
-    u32 *row = counts + (u64)d * nb;
-    u32 c[4], sum = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const u32 i = tid * 4 + j;
-        c[j] = i < nb ? row[i] : 0;
-        sum += c[j];
-    }
-    u32 inc = sum;
-    for (int o = 1; o < 64; o <<= 1) {
-        u32 v = __shfl_up(inc, o);
-        if (lane >= o) inc += v;
-    }
-    if (lane == 0) wave_a[wid] = below;
-    if (lane == 63) wave_b[wid] = inc;
-    __syncthreads();
-    u32 run = wave_a[0] + wave_a[1] + wave_a[2] + wave_a[3] + inc - sum;
-    for (u32 w = 0; w < wid; ++w) run += wave_b[w];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const u32 i = tid * 4 + j;
-        if (i < nb) row[i] = run;
-        run += c[j];
-    }
-}
-
-// ---- per pass: stable scatter -----------------------------------------------------------------
-__global__ void __launch_bounds__(SORT_THREADS) k_scatter(const Plan *__restrict__ plan, int pass, const u64 *in,
-                                                           u64 *a, u64 *b, u64 n, u64 chunk,
-                                                           const u32 *__restrict__ counts) {
+// ---- one radix pass, one kernel (onesweep) -------------------------------------------------------
+// Tiles are handed out by ticket, so every tile a workgroup waits for belongs to a workgroup that
+// started earlier and never waits for a later one: the look-back cannot deadlock.  The spin is
+// nevertheless bounded; if the bound is ever hit the error word is set and k_positions poisons the
+// output with NaN (loud, not a hang).  Look-back words are written and read with agent-scope
+// atomics (the per-XCD L2s are not coherent with each other); nothing else crosses workgroups.
+__global__ void __launch_bounds__(SORT_THREADS) k_onesweep(const Plan *__restrict__ plan, int pass, const u64 *in,
+                                                            u64 *a, u64 *b, u64 n, u32 tiles,
+                                                            const u32 *__restrict__ hist, u32 *ticket, u32 *err,
+                                                            u64 *lookback) {
     if (plan->skip[pass]) return;
     const u64 *src = pick_src(plan->src[pass], in, a, b);
     u64 *dst = plan->dst[pass] == 1 ? a : b;
+    u64 *lb = lookback + (u64)plan->slot[pass] * tiles * 256;
+    u64 *lb_next = lookback + (u64)(1u - plan->slot[pass]) * tiles * 256;
     __shared__ u64 stage[SORT_TILE];
     __shared__ u32 wcnt[4][256];   // per-wave digit counts of the tile, then exclusive prefix over waves
-    __shared__ u32 base[256];      // running global write offset of each digit for this workgroup
+    __shared__ u64 base[256];      // global write offset of each digit for this tile
     __shared__ u32 tile_off[256];  // exclusive scan of the tile's digit counts
     __shared__ u32 wave_sum[4];
+    __shared__ u32 wave_below[4];
+    __shared__ u32 tile_s;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    base[tid] = counts[(u64)tid * gridDim.x + blockIdx.x];
-    const u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
-    for (u64 t0 = lo; t0 < hi; t0 += SORT_TILE) {
-        const u32 tile_n = (u32)min((u64)SORT_TILE, hi - t0);
-        for (int w = 0; w < 4; ++w) wcnt[w][tid] = 0;
-        __syncthreads();
-        // each wave owns 1024 consecutive keys of the tile: order = (wave, round, lane)
-        u64 key[SORT_ITEMS];
-        u32 rank[SORT_ITEMS];
+    if (tid == 0) tile_s = atomicAdd(&ticket[pass], 1u);
+    for (int w = 0; w < 4; ++w) wcnt[w][tid] = 0;
+    __syncthreads();
+    const u32 tile = tile_s;
+    const u64 t0 = (u64)tile * SORT_TILE;
+    const u32 tile_n = (u32)min((u64)SORT_TILE, n - t0);
+    lb_next[(u64)tile * 256 + tid] = 0;  // the next active pass starts from clean words
+
+    // each wave owns 1024 consecutive keys of the tile: order = (wave, round, lane)
+    u64 key[SORT_ITEMS];
+    u32 rank[SORT_ITEMS];
 #pragma unroll
-        for (int r = 0; r < SORT_ITEMS; ++r) {
-            const u32 j = wid * (64 * SORT_ITEMS) + r * 64 + lane;
-            const bool valid = j < tile_n;
-            key[r] = valid ? src[t0 + j] : ~0ull;
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const u32 j = wid * (64 * SORT_ITEMS) + r * 64 + lane;
+        key[r] = j < tile_n ? src[t0 + j] : ~0ull;
+    }
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const u32 j = wid * (64 * SORT_ITEMS) + r * 64 + lane;
+        const bool valid = j < tile_n;
+        const u32 d = digit_of(key[r], pass);
+        // lanes of this wave holding the same digit (invalid lanes match nobody)
+        u64 peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const u64 vote = __ballot((d >> bit) & 1u);
+            peers &= ((d >> bit) & 1u) ? vote : ~vote;
+        }
+        const u32 before = __popcll(peers & ((1ull << lane) - 1ull));
+        const u32 cnt = __popcll(peers);
+        const int leader = __ffsll((long long)peers) - 1;
+        u32 old = 0;
+        if (valid && lane == leader) old = atomicAdd(&wcnt[wid][d], cnt);
+        old = __shfl(old, leader < 0 ? 0 : leader);
+        rank[r] = old + before;
+    }
+    __syncthreads();
+    // digit `tid`: exclusive prefix over the 4 waves, tile total
+    const u32 c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid], c3 = wcnt[3][tid];
+    const u32 tot = c0 + c1 + c2 + c3;
+    u64 *mine = lb + (u64)tile * 256 + tid;
+    __hip_atomic_store(mine, (u64)tot | (tile == 0 ? LB_INCL : LB_LOCAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    wcnt[0][tid] = 0;
+    wcnt[1][tid] = c0;
+    wcnt[2][tid] = c0 + c1;
+    wcnt[3][tid] = c0 + c1 + c2;
+    // exclusive scans over the 256 digits: of the tile's counts and of the global histogram
+    u32 inc = tot, ginc = hist[pass * 256 + tid];
+    const u32 gown = ginc;
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 v = __shfl_up(inc, o), g = __shfl_up(ginc, o);
+        if (lane >= o) {
+            inc += v;
+            ginc += g;
+        }
+    }
+    if (lane == 63) {
+        wave_sum[wid] = inc;
+        wave_below[wid] = ginc;
+    }
+    __syncthreads();
+    u32 woff = 0, gbelow = 0;
+    for (int w = 0; w < wid; ++w) {
+        woff += wave_sum[w];
+        gbelow += wave_below[w];
+    }
+    tile_off[tid] = woff + inc - tot;
+    // decoupled look-back: keys of digit `tid` in all earlier tiles
+    u64 excl = 0;
+    if (tile > 0) {
+        u32 spins = 0;
+        for (u32 p = tile; p-- > 0;) {
+            const u64 *w = lb + (u64)p * 256 + tid;
+            u64 v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while ((v & ~LB_MASK) == 0) {
+                if (++spins > LB_SPIN_LIMIT) {
+                    atomicOr(err, 1u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            excl += v & LB_MASK;
+            if ((v & ~LB_MASK) != LB_LOCAL) break;  // inclusive (or gave up)
+        }
+        __hip_atomic_store(mine, (excl + tot) | LB_INCL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    base[tid] = (u64)(gbelow + ginc - gown) + excl;
+    __syncthreads();
+    // stage keys in LDS in digit order
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const u32 j = wid * (64 * SORT_ITEMS) + r * 64 + lane;
+        if (j < tile_n) {
             const u32 d = digit_of(key[r], pass);
-            // lanes of this wave holding the same digit (invalid lanes match nobody)
-            u64 peers = __ballot(valid);
-#pragma unroll
-            for (int bit = 0; bit < 8; ++bit) {
-                const u64 vote = __ballot((d >> bit) & 1u);
-                peers &= ((d >> bit) & 1u) ? vote : ~vote;
-            }
-            const u32 before = __popcll(peers & ((1ull << lane) - 1ull));
-            const u32 cnt = __popcll(peers);
-            const int leader = __ffsll((long long)peers) - 1;
-            u32 old = 0;
-            if (valid && lane == leader) old = atomicAdd(&wcnt[wid][d], cnt);
-            old = __shfl(old, leader < 0 ? 0 : leader);
-            rank[r] = old + before;
+            stage[tile_off[d] + wcnt[wid][d] + rank[r]] = key[r];
         }
-        __syncthreads();
-        // digit `tid`: exclusive prefix over the 4 waves, tile total
-        u32 c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid], c3 = wcnt[3][tid];
-        const u32 tot = c0 + c1 + c2 + c3;
-        wcnt[0][tid] = 0;
-        wcnt[1][tid] = c0;
-        wcnt[2][tid] = c0 + c1;
-        wcnt[3][tid] = c0 + c1 + c2;
-        // exclusive scan of tot over the 256 digits
-        u32 inc = tot;
-        for (int o = 1; o < 64; o <<= 1) {
-            u32 v = __shfl_up(inc, o);
-            if (lane >= o) inc += v;
-        }
-        if (lane == 63) wave_sum[wid] = inc;
-        __syncthreads();
-        u32 woff = 0;
-        for (int w = 0; w < wid; ++w) woff += wave_sum[w];
-        tile_off[tid] = woff + inc - tot;
-        __syncthreads();
-        // stage keys in LDS in digit order
-#pragma unroll
-        for (int r = 0; r < SORT_ITEMS; ++r) {
-            const u32 j = wid * (64 * SORT_ITEMS) + r * 64 + lane;
-            if (j < tile_n) {
-                const u32 d = digit_of(key[r], pass);
-                stage[tile_off[d] + wcnt[wid][d] + rank[r]] = key[r];
-            }
-        }
-        __syncthreads();
-        // digit-contiguous runs out to global
-        for (u32 j = tid; j < tile_n; j += SORT_THREADS) {
-            const u64 k = stage[j];
-            const u32 d = digit_of(k, pass);
-            dst[(u64)base[d] + (j - tile_off[d])] = k;
-        }
-        __syncthreads();
-        base[tid] += tot;
-        // (the next iteration's first __syncthreads orders this against its readers)
+    }
+    __syncthreads();
+    // digit-contiguous runs out to global
+    for (u32 j = tid; j < tile_n; j += SORT_THREADS) {
+        const u64 k = stage[j];
+        const u32 d = digit_of(k, pass);
+        dst[base[d] + (j - tile_off[d])] = k;
     }
 }
 
@@ -304,10 +320,11 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_partials(double *partials
 
 __global__ void __launch_bounds__(SCAN_THREADS) k_positions(const double *__restrict__ keys, u64 n, u64 chunk,
                                                              double logn, const double *__restrict__ partials,
-                                                             double *__restrict__ pos) {
+                                                             const u32 *__restrict__ err, double *__restrict__ pos) {
     __shared__ double wave_tot[SCAN_THREADS / 64];
     const u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
-    double carry = partials[blockIdx.x];
+    // a sort pass that gave up waiting (k_onesweep) must not pass for a result
+    double carry = *err ? __longlong_as_double(0x7FF8000000000000ll) : partials[blockIdx.x];
     for (u64 t0 = lo; t0 < hi; t0 += SCAN_TILE) {
         // lane owns SCAN_ITEMS consecutive keys
         const u64 i0 = t0 + (u64)threadIdx.x * SCAN_ITEMS;
@@ -346,10 +363,8 @@ __global__ void __launch_bounds__(256) k_query(const double *__restrict__ keys, 
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-u32 sort_blocks(u64 n) {
-    u64 tiles = (n + SORT_TILE - 1) / SORT_TILE;
-    return (u32)(tiles < (u64)SORT_MAX_BLOCKS ? (tiles ? tiles : 1) : SORT_MAX_BLOCKS);
-}
+u32 sort_tiles(u64 n) { return (u32)((n + SORT_TILE - 1) / SORT_TILE); }
+constexpr size_t HIST_WORDS = 8 * 256 + 8 + 8;  // histograms, tickets, error word (+pad)
 u32 scan_blocks(u64 n) {
     u64 tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     return (u32)(tiles < (u64)SCAN_MAX_BLOCKS ? (tiles ? tiles : 1) : SCAN_MAX_BLOCKS);
@@ -358,8 +373,8 @@ u32 scan_blocks(u64 n) {
 }  // namespace
 
 extern "C" size_t mc_rank_workspace_bytes(uint64_t n) {
-    return align256(n * sizeof(u64)) + align256(8 * 256 * sizeof(u32)) +
-           align256((size_t)256 * SORT_MAX_BLOCKS * sizeof(u32)) + align256(sizeof(Plan)) +
+    return align256(n * sizeof(u64)) + align256(HIST_WORDS * sizeof(u32)) +
+           align256((size_t)2 * sort_tiles(n) * 256 * sizeof(u64)) + align256(sizeof(Plan)) +
            align256(SCAN_MAX_BLOCKS * sizeof(double));
 }
 
@@ -384,17 +399,21 @@ extern "C" int mc_rank_build(const double *keys_in, uint64_t n, uint64_t n_globa
     SortWs ws;
     ws.temp = (u64 *)p;
     p += align256(n * sizeof(u64));
+    const u32 tiles = sort_tiles(n);
+    const size_t lb_bytes = (size_t)2 * tiles * 256 * sizeof(u64);
     ws.hist = (u32 *)p;
-    p += align256(8 * 256 * sizeof(u32));
-    ws.counts = (u32 *)p;
-    p += align256((size_t)256 * SORT_MAX_BLOCKS * sizeof(u32));
+    p += align256(HIST_WORDS * sizeof(u32));
+    ws.lookback = (u64 *)p;
+    p += align256(lb_bytes);
     ws.plan = (Plan *)p;
     p += align256(sizeof(Plan));
     ws.partials = (double *)p;
+    u32 *ticket = ws.hist + 8 * 256, *err = ws.hist + 8 * 256 + 8;
 
     const u64 *in = (const u64 *)keys_in;
     u64 *A = (u64 *)keys_sorted, *B = ws.temp;
-    HIP_TRY(hipMemsetAsync(ws.hist, 0, 8 * 256 * sizeof(u32), s));
+    // histograms, tickets, error word and both look-back regions are contiguous: one clear
+    HIP_TRY(hipMemsetAsync(ws.hist, 0, align256(HIST_WORDS * sizeof(u32)) + lb_bytes, s));
     {
         u64 want = (n + 255) / 256;
         u32 g = (u32)(want < 2048 ? want : 2048);
@@ -402,16 +421,9 @@ extern "C" int mc_rank_build(const double *keys_in, uint64_t n, uint64_t n_globa
         hipLaunchKernelGGL(k_plan, dim3(1), dim3(256), 0, s, ws.hist, (u64)n, ws.plan);
         hipLaunchKernelGGL(k_copy_if_unsorted, dim3(g), dim3(256), 0, s, ws.plan, in, A, (u64)n);
     }
-    const u32 nb = sort_blocks(n);
-    const u64 tiles = (n + SORT_TILE - 1) / SORT_TILE;
-    const u64 chunk = ((tiles + nb - 1) / nb) * SORT_TILE;  // whole tiles per workgroup
-    for (int pass = 0; pass < 8; ++pass) {
-        hipLaunchKernelGGL(k_count, dim3(nb), dim3(SORT_THREADS), 0, s, ws.plan, pass, in, (const u64 *)A,
-                           (const u64 *)B, (u64)n, chunk, ws.counts);
-        hipLaunchKernelGGL(k_scan_counts, dim3(256), dim3(256), 0, s, ws.plan, pass, ws.counts, nb, (const u32 *)ws.hist);
-        hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(SORT_THREADS), 0, s, ws.plan, pass, in, A, B, (u64)n, chunk,
-                           ws.counts);
-    }
+    for (int pass = 0; pass < 8; ++pass)
+        hipLaunchKernelGGL(k_onesweep, dim3(tiles), dim3(SORT_THREADS), 0, s, ws.plan, pass, in, A, B, (u64)n, tiles,
+                           (const u32 *)ws.hist, ticket, err, ws.lookback);
     // positions
     const double logn = std::log2((double)n_global);
     const u32 sb = scan_blocks(n);
@@ -421,7 +433,7 @@ extern "C" int mc_rank_build(const double *keys_in, uint64_t n, uint64_t n_globa
                        logn, ws.partials);
     hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(SCAN_THREADS), 0, s, ws.partials, sb);
     hipLaunchKernelGGL(k_positions, dim3(sb), dim3(SCAN_THREADS), 0, s, (const double *)keys_sorted, (u64)n, schunk,
-                       logn, (const double *)ws.partials, positions);
+                       logn, (const double *)ws.partials, (const u32 *)err, positions);
     HIP_TRY(hipGetLastError());
     return MC_OK;
 }

@@ -233,7 +233,7 @@ extern "C" int mc_table_compile(const mc_model_desc *d, mc_table **out) {
         delete t;
         return MC_ERR_TABLE;
     }
-    uint32_t gf = d->guide_factor ? d->guide_factor : 2;
+    uint32_t gf = d->guide_factor ? d->guide_factor : 4;
     t->state.resize(d->n_ctx);
     t->cum.assign(d->ent_cum, d->ent_cum + d->n_ent);
     t->payload.resize(d->n_ent);

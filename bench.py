@@ -33,9 +33,23 @@ from montecarlo_amd import _native as nv  # noqa: E402
 from montecarlo_amd import dist as mcd  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-# algorithmic bytes of one draw in k_sample (DESIGN.md "Sampling kernel"): state record 32 B,
-# guide bucket 8 B, payload 16 B, plus 8 B per cum[] comparison; 8 B key written per sample
-B_DRAW, B_PROBE, B_SAMPLE = 32 + 8 + 16, 8, 8
+# HBM bytes per launch from the last committed PMC passes (profiles/r01_*_pmc_hbm_traffic.json: FETCH_SIZE
+# doubled per the guide's gfx950 correction + WRITE_SIZE, separate rocprofv3 --pmc runs of this same
+# command).  They are measured by scripts/gpu_round.sh, not inside this process; null when absent.
+TRAFFIC = {}
+try:
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic_latest.json")) as _f:
+        TRAFFIC = json.load(_f)
+except (OSError, ValueError):
+    pass
+# algorithmic bytes of k_sample: one 16-B draw-table record per draw, one more 16-B
+# record for a draw whose bucket straddles a threshold, 8 B per threshold read from RCUM (counted
+# from the compare counter: an upper bound, single-threshold buckets compare without a read),
+# 8 B key written per sample.  All counts come from the device counters of the timed launches.
+B_DRAW, B_INDIRECT, B_PROBE, B_SAMPLE = 16, 16, 8, 8
+# rank build: 8 B/key histogram read + 16 B/key per ACTIVE radix pass + 8 B/key
+# weight sums + 16 B/key positions
+B_HIST, B_PASS, B_SCAN = 8, 16, 24
 
 
 def main():
@@ -126,10 +140,17 @@ def main():
     # sanity on the last step (not timed): finite keys, sorted output
     assert bool(torch.isfinite(keys).all()) and bool((keys_sorted[1:] >= keys_sorted[:-1]).all())
 
+    # radix passes that do anything on the last step's keys (mc_rank_build skips constant digits)
+    kb = keys.view(torch.uint8).view(N, 8)
+    active = int(sum(int(kb[:, b].min()) != int(kb[:, b].max()) for b in range(8)))
+
     if rank == 0:
         draws, probes = cnt["draws"] / args.steps, cnt["cdf_probes"] / args.steps
-        bytes_per_launch = draws * B_DRAW + probes * B_PROBE + N * B_SAMPLE
+        indirect = cnt["indirect_draws"] / args.steps
+        bytes_per_launch = draws * B_DRAW + indirect * B_INDIRECT + probes * B_PROBE + N * B_SAMPLE
         achieved = bytes_per_launch / (ms["sample"] * 1e-3) / 1e9
+        rank_bytes = N * (B_HIST + B_PASS * active + B_SCAN)
+        rank_achieved = rank_bytes / (ms["rank"] * 1e-3) / 1e9
         out = {
             "metric": "sampled passwords/sec (node) + guess numbers/sec, 4-gram backoff, 1/2/4/8 GPU",
             "value": N * world * args.steps / dt,
@@ -145,10 +166,18 @@ def main():
             "stage_ms": ms,
             "sampling_only_per_s": N * world / (ms["sample"] * 1e-3),
             "guess_numbers_per_s": T / ((ms["score"] + ms["query"]) * 1e-3),
-            "draws_per_sample": draws / N, "cdf_probes_per_draw": probes / max(draws, 1),
+            "draws_per_sample": draws / N, "indirect_draws_per_draw": indirect / max(draws, 1),
+            "threshold_compares_per_draw": probes / max(draws, 1),
+            # the longest single launch; HBM traffic from profiles/*pmc_hbm_traffic.json (rocprofv3 --pmc)
             "roofline": {"bound": "hbm", "kernel": "k_sample", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC.get("k_sample"),
                          "bytes_per_launch": bytes_per_launch, "kernel_ms": ms["sample"]},
+            # the rank build as a whole (hist + onesweep passes + scan: 13 launches, timed together)
+            "roofline_rank_build": {"bound": "hbm", "kernel": "mc_rank_build (k_hist_all, k_onesweep x active "
+                                    "passes, k_weight_sums, k_positions)", "achieved": rank_achieved,
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rank_achieved / HBM_PEAK_GBS,
+                                    "traffic": TRAFFIC.get("mc_rank_build"), "bytes_per_launch": rank_bytes,
+                                    "active_passes": active, "kernel_ms": ms["rank"]},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, test, args.cpu_samples)

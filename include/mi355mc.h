@@ -81,6 +81,11 @@ typedef struct mc_model_desc {
     uint32_t max_len;       /* restart when pwd_len >= max_len (nwords_simulator.py:112): 256 */
     uint32_t flags;         /* MC_FLAG_* */
     uint32_t guide_factor;  /* draw-table buckets per row ~ guide_factor * row length, rounded up to 2^k (0 -> 4) */
+    /* text of every transition symbol as Unicode code points (symbol s = sym_text[sym_text_off[s] ..
+     * sym_text_off[s+1])): what `left in self.words` / `left in row` compare against in _structures
+     * (nwords_simulator.py:42-45).  NULL: mc_score_words is unavailable for the model. */
+    const uint32_t *sym_text_off; /* [n_sym+1] or NULL */
+    const uint32_t *sym_text;
 } mc_model_desc;
 
 typedef struct mc_table mc_table; /* compiled table, host memory */
@@ -110,7 +115,10 @@ enum {
     MC_ARR_CTXHASH = 5,  /* mc_slot[ctx_cap]: key = 64-bit context hash, val = row */
     MC_ARR_SYMCHARS = 6, /* uint32[n_sym] */
     MC_ARR_SPAY = 7,     /* mc_draw_rec[n_ent]: MC_DRAW_DIRECT record of every entry (sampling) */
-    MC_ARR_RCUM = 8      /* double[n_ent]: per-entry thresholds in the uniform's domain (see mc_draw_rec) */
+    MC_ARR_RCUM = 8,     /* double[n_ent]: per-entry thresholds in the uniform's domain (see mc_draw_rec) */
+    MC_ARR_WORDHASH = 9, /* mc_slot[word_cap]: key = mc_text_hash(symbol text), val = symbol id, pad = length */
+    MC_ARR_SYMTEXTOFF = 10, /* uint32[n_sym+1] */
+    MC_ARR_SYMTEXT = 11  /* uint32[]: code points */
 };
 int64_t mc_table_array(const mc_table *t, int what, void *dst, size_t cap);
 /* start state, end symbol, root (zero-gram) row, table sizes ... as 16 uint64 (see mc_table_info_idx) */
@@ -120,9 +128,11 @@ enum {
     MC_INFO_TRANS_CAP = 5, MC_INFO_CTX_CAP = 6, MC_INFO_GUIDE_LEN = 7, MC_INFO_DEVICE_BYTES = 8,
     MC_INFO_MAX_ROW = 9, MC_INFO_KIND = 10, MC_INFO_MULTICHAR = 11, MC_INFO_START_DRAW = 12,
     MC_INFO_DIRECT_BUCKETS = 13, MC_INFO_ONE_BUCKETS = 14, MC_INFO_MULTI_BUCKETS = 15
-};
+};  /* info[11] (MC_INFO_MULTICHAR) bit 0: some symbol is not one character; bits 8..: longest symbol text */
 /* 64-bit hash of a context (sequence of unit ids) as stored in the context index. */
 uint64_t mc_ctx_hash(const uint32_t *units, uint32_t n);
+/* 64-bit hash of a symbol's text (code points) as stored in the word index. */
+uint64_t mc_text_hash(const uint32_t *cps, uint32_t n);
 
 /* Flat record layouts (also the device layouts). */
 typedef struct mc_state_rec {
@@ -212,6 +222,22 @@ int mc_sample_injected(mc_model *m, uint64_t count, const double *uniforms, uint
  * no parse (nwords_simulator.py:85). */
 int mc_score(mc_model *m, const uint32_t *syms, const uint64_t *off, uint64_t count, double *out_ml2p,
              void *stream);
+
+/* ---- scoring, any alphabet: calc_ml2p as the reference's DFS over every segmentation of
+ * pwd + end_chr into symbols (`_structures`, nwords_simulator.py:36-60, called from :84-90 and
+ * backwords_simulator.py:43-49): the MINIMUM over full parses of the left-to-right sum of -log2 p,
+ * exploring split lengths in ascending order and honouring iter_max exactly as the recursion does
+ * (a callee returns at once when iter_max full parses have been seen; callers go on with their
+ * remaining splits).  Password t is the code points cps[off[t] .. off[t+1]); the end symbol's text
+ * is appended by the kernel.  out_ml2p[t] = that minimum, or 1022.0 when there is no parse.
+ * out_split (may be NULL) receives split_words u64 per password: bit j set = a symbol of the best
+ * parse ends after character j+1 of pwd + end_chr (all zero when unparseable).  max_len = an upper
+ * bound on the password lengths of the batch (the DFS stack lives in `workspace`); a longer
+ * password yields NaN and is reported by mc_model_check as a failed item. */
+size_t mc_score_words_workspace_bytes(const mc_model *m, uint64_t count, uint32_t max_len);
+int mc_score_words(mc_model *m, const uint32_t *cps, const uint64_t *off, uint64_t count, uint32_t max_len,
+                   uint64_t iter_max, double *out_ml2p, uint64_t *out_split, uint32_t split_words,
+                   void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- rank estimation: MonteCarloLib.__init__ (lib4mc/MonteCarloLib.py:10-28): sort the
  * sampled -log2 p ascending, positions = cumsum(2^(key - log2 n_global)).  keys_sorted and

@@ -19,7 +19,8 @@ LIB_PATH = os.path.join(_HERE, "libmi355mc.so")
 MC_NONE = 0xFFFFFFFF
 KIND_NGRAM, KIND_BACKOFF, KIND_V2 = 1, 2, 3
 FLAG_KEEP_LEN_ON_RESTART = 1
-(ARR_STATE, ARR_DRAW, ARR_CUM, ARR_PAYLOAD, ARR_TRANS, ARR_CTXHASH, ARR_SYMCHARS, ARR_SPAY, ARR_RCUM) = range(9)
+(ARR_STATE, ARR_DRAW, ARR_CUM, ARR_PAYLOAD, ARR_TRANS, ARR_CTXHASH, ARR_SYMCHARS, ARR_SPAY, ARR_RCUM, ARR_WORDHASH,
+ ARR_SYMTEXTOFF, ARR_SYMTEXT) = range(12)
 (INFO_NCTX, INFO_NENT, INFO_NSYM, INFO_START_STATE, INFO_ROOT, INFO_TRANS_CAP, INFO_CTX_CAP, INFO_GUIDE_LEN,
  INFO_DEVICE_BYTES, INFO_MAX_ROW, INFO_KIND, INFO_MULTICHAR, INFO_START_DRAW, INFO_DIRECT_BUCKETS,
  INFO_ONE_BUCKETS, INFO_MULTI_BUCKETS) = range(16)
@@ -41,6 +42,7 @@ class ModelDesc(C.Structure):
         ("start_units", u32p), ("n_start", C.c_uint32),
         ("end_sym", C.c_uint32), ("min_len", C.c_uint32), ("max_len", C.c_uint32), ("flags", C.c_uint32),
         ("guide_factor", C.c_uint32),
+        ("sym_text_off", u32p), ("sym_text", u32p),
     ]
 
 
@@ -65,12 +67,16 @@ def _load() -> C.CDLL:
         "mc_table_array": (C.c_int64, [vp, C.c_int, vp, C.c_size_t]),
         "mc_table_info": (C.c_int, [vp, u64p]),
         "mc_ctx_hash": (C.c_uint64, [u32p, C.c_uint32]),
+        "mc_text_hash": (C.c_uint64, [u32p, C.c_uint32]),
         "mc_model_upload": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
         "mc_model_destroy": (None, [vp]),
         "mc_model_check": (C.c_int, [vp, vp, u64p]),
         "mc_sample": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, vp, vp, vp, vp, C.c_uint32, vp]),
         "mc_sample_injected": (C.c_int, [vp, C.c_uint64, vp, C.c_uint32, vp, vp, vp, vp, C.c_uint32, vp]),
         "mc_score": (C.c_int, [vp, vp, vp, C.c_uint64, vp, vp]),
+        "mc_score_words_workspace_bytes": (C.c_size_t, [vp, C.c_uint64, C.c_uint32]),
+        "mc_score_words": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint64, vp, vp, C.c_uint32, vp,
+                                     C.c_size_t, vp]),
         "mc_rank_workspace_bytes": (C.c_size_t, [C.c_uint64]),
         "mc_rank_build": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, vp, vp, C.c_size_t, vp]),
         "mc_rank_query": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp]),
@@ -83,7 +89,7 @@ def _load() -> C.CDLL:
 
 lib = _load()
 EXPORTS = ["mc_abi_version", "mc_last_error", "mc_table_compile", "mc_table_free", "mc_table_array", "mc_table_info",
-           "mc_ctx_hash", "mc_model_upload", "mc_model_destroy", "mc_model_check", "mc_sample", "mc_sample_injected",
+           "mc_ctx_hash", "mc_text_hash", "mc_score_words_workspace_bytes", "mc_score_words", "mc_model_upload", "mc_model_destroy", "mc_model_check", "mc_sample", "mc_sample_injected",
            "mc_score", "mc_rank_workspace_bytes", "mc_rank_build", "mc_rank_query"]
 
 

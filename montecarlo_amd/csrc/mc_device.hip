@@ -57,10 +57,14 @@ struct DevModel {
     const Slot *trans;
     const Slot *ctxhash;
     const uint32_t *sym_chars;
+    const Slot *wordhash;
+    const uint32_t *sym_text_off, *sym_text;
     unsigned long long *status;
     unsigned long long trans_mask, ctx_mask;
     uint32_t start_state, root, end_sym, min_len, max_len, flags, n_ctx, n_sym;
     uint32_t start_draw, start_gbits;
+    unsigned long long word_mask;
+    uint32_t max_word_len, start_sym, end_text_off, end_text_len;
 };
 
 struct SampleArgs {
@@ -357,6 +361,144 @@ __global__ void __launch_bounds__(256) k_score(DevModel m, const uint32_t *__res
     }
 }
 
+// ---- calc_ml2p for any alphabet: the DFS of _structures (nwords_simulator.py:36-60) with an
+// explicit stack, one lane per password.  A frame is one activation of _structures: the offset its
+// `pwd` argument starts at, the next split length to try, the automaton state (the row for the
+// container so far) and the running sum of -log2 p.  sum([..]) in the reference adds left to
+// right from 0, which is the same chain of fp64 additions as the running sum.
+struct alignas(16) Frame {
+    double acc;
+    uint32_t state;
+    uint16_t pos, idx;
+};
+
+struct WordsArgs {
+    const uint32_t *cps;
+    const unsigned long long *off;
+    unsigned long long count, iter_max;
+    double *out;
+    unsigned long long *out_split;
+    Frame *stack;
+    uint32_t split_words, max_len, n_lanes;
+};
+
+__device__ __forceinline__ uint32_t find_entry(const DevModel &m, uint32_t state, uint32_t s, unsigned int &c_probe) {
+    uint32_t row = state;
+    while (row != MC_NONE) {  // longest suffix row that lists s (backwords_simulator.py:31-38)
+        const unsigned long long key = ((unsigned long long)row << 32) | s;
+        unsigned long long q = mix64(key + 0x9E3779B97F4A7C15ull) & m.trans_mask;
+        for (;;) {
+            const Slot sl = m.trans[q];
+            ++c_probe;
+            if (sl.key == key) return sl.val;
+            if (sl.key == ~0ull) break;
+            q = (q + 1) & m.trans_mask;
+        }
+        row = m.state[row].parent;
+    }
+    return MC_NONE;
+}
+
+__global__ void __launch_bounds__(256) k_score_words(DevModel m, WordsArgs a) {
+    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned int c_probe = 0, c_step = 0, c_long = 0;
+    Frame *st = a.stack + lane;  // frame of depth L at st[L * n_lanes]
+    const size_t fs = a.n_lanes;
+    for (unsigned long long t = lane; t < a.count; t += a.n_lanes) {
+        const unsigned long long p0 = a.off[t];
+        const uint32_t len = (uint32_t)(a.off[t + 1] - p0);
+        if (a.out_split)
+            for (uint32_t w = 0; w < a.split_words; ++w) a.out_split[t * a.split_words + w] = 0;
+        if (len > a.max_len) {
+            a.out[t] = __longlong_as_double(0x7FF8000000000000ll);
+            ++c_long;
+            continue;
+        }
+        const uint32_t total = len + m.end_text_len;  // len(pwd) + len(end_chr)
+        auto ch = [&](uint32_t j) -> uint32_t {
+            return j < len ? a.cps[p0 + j] : m.sym_text[m.end_text_off + (j - len)];
+        };
+        double best = 1022.0;
+        unsigned long long done = 0;
+        uint32_t depth = 0;
+        if (a.iter_max > 0) {  // the entry check of the outermost call (:39)
+            st[0] = Frame{0.0, m.start_state, 0, 1};
+            depth = 1;
+        }
+        while (depth > 0) {
+            Frame f = st[(depth - 1) * fs];
+            const uint32_t rest = total - f.pos;
+            const uint32_t top = rest < m.max_word_len ? rest : m.max_word_len;  // no symbol is longer
+            unsigned long long h = 0xCBF29CE484222325ull;
+            for (uint32_t j = 0; j + 1 < f.idx && j < top; ++j) h = (h ^ ch(f.pos + j)) * 0x100000001B3ull;
+            bool advanced = false;
+            for (uint32_t idx = f.idx; idx <= top; ++idx) {
+                h = (h ^ ch(f.pos + idx - 1)) * 0x100000001B3ull;
+                // `left in self.words`: the symbol whose text is text[pos : pos + idx]
+                uint32_t sym = MC_NONE;
+                {
+                    const unsigned long long key = h == ~0ull ? ~0ull - 1 : h;
+                    for (unsigned long long q = key & m.word_mask;; q = (q + 1) & m.word_mask) {
+                        const Slot sl = m.wordhash[q];
+                        if (sl.key == ~0ull) break;
+                        if (sl.key == key && sl.pad == idx) {
+                            const uint32_t *txt = m.sym_text + m.sym_text_off[sl.val];
+                            bool same = true;
+                            for (uint32_t j = 0; j < idx; ++j) same = same && txt[j] == ch(f.pos + j);
+                            if (same) {
+                                sym = sl.val;
+                                break;
+                            }
+                        }
+                    }
+                }
+                // a start symbol is dropped from the components (:50), so a parse through it never
+                // reaches target_len: that subtree neither changes the minimum nor the parse count
+                if (sym == MC_NONE || sym == m.start_sym) continue;
+                const uint32_t e = find_entry(m, f.state, sym, c_probe);
+                if (e == MC_NONE) continue;
+                const Payload p = m.payload[e];
+                const double nacc = f.acc + p.ml2p;
+                ++c_step;
+                st[(depth - 1) * fs].idx = (uint16_t)(idx + 1);
+                if (f.pos + idx == total) {  // a full parse (:51-56)
+                    if (best > nacc) {
+                        best = nacc;
+                        if (a.out_split) {
+                            unsigned long long *sp = a.out_split + t * a.split_words;
+                            for (uint32_t w = 0; w < a.split_words; ++w) sp[w] = 0;
+                            for (uint32_t l = 0; l < depth; ++l) {
+                                const Frame g = st[l * fs];
+                                const uint32_t end = g.pos + g.idx - 1u;  // idx already points past the split taken
+                                if (((end - 1) >> 6) < a.split_words) sp[(end - 1) >> 6] |= 1ull << ((end - 1) & 63);
+                            }
+                        }
+                    }
+                    ++done;
+                }
+                if (done < a.iter_max) {  // the callee's entry check (:39)
+                    st[depth * fs] = Frame{nacc, p.next, (uint16_t)(f.pos + idx), 1};
+                    ++depth;
+                }
+                advanced = true;
+                break;
+            }
+            if (!advanced) --depth;
+        }
+        a.out[t] = best;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        c_probe += __shfl_down(c_probe, o);
+        c_step += __shfl_down(c_step, o);
+        c_long += __shfl_down(c_long, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&m.status[MC_CNT_SCORE_PROBES], (unsigned long long)c_probe);
+        atomicAdd(&m.status[MC_CNT_SCORE_STEPS], (unsigned long long)c_step);
+        if (c_long) atomicAdd(&m.status[MC_CNT_SCORE_TOO_LONG], (unsigned long long)c_long);
+    }
+}
+
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 }  // namespace
@@ -364,6 +506,7 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 struct mc_model {
     int device;
     int n_cu;
+    bool has_text;
     void *arena;
     size_t arena_bytes;
     DevModel dev;
@@ -383,6 +526,7 @@ extern "C" int mc_model_upload(const mc_table *t, int device, mc_model **out) {
     if (!m) return MC_ERR_NOMEM;
     m->device = device;
     m->multichar = t->multichar;
+    m->has_text = !t->wordhash.empty();
     m->arena_bytes = mc_table_device_bytes(t);
     hipError_t e = hipMalloc(&m->arena, m->arena_bytes);
     if (e != hipSuccess) {
@@ -408,6 +552,14 @@ extern "C" int mc_model_upload(const mc_table *t, int device, mc_model **out) {
     d.trans = (const Slot *)put(t->trans.data(), t->trans.size() * sizeof(mc_slot));
     d.ctxhash = (const Slot *)put(t->ctxhash.data(), t->ctxhash.size() * sizeof(mc_slot));
     d.sym_chars = (const uint32_t *)put(t->sym_chars.data(), t->sym_chars.size() * sizeof(uint32_t));
+    d.wordhash = (const Slot *)put(t->wordhash.data(), t->wordhash.size() * sizeof(mc_slot));
+    d.sym_text_off = (const uint32_t *)put(t->sym_text_off.data(), t->sym_text_off.size() * sizeof(uint32_t));
+    d.sym_text = (const uint32_t *)put(t->sym_text.data(), t->sym_text.size() * sizeof(uint32_t));
+    d.word_mask = t->wordhash.empty() ? 0 : t->wordhash.size() - 1;
+    d.max_word_len = t->max_word_len;
+    d.start_sym = t->start_sym;
+    d.end_text_off = t->sym_text_off.empty() ? 0 : t->sym_text_off[t->end_sym];
+    d.end_text_len = t->sym_text_off.empty() ? 0 : t->sym_text_off[t->end_sym + 1] - t->sym_text_off[t->end_sym];
     d.status = (unsigned long long *)p;
     HIP_TRY(hipMemset(d.status, 0, MC_STATUS_WORDS * sizeof(uint64_t)));
     HIP_TRY(hipDeviceSynchronize());
@@ -446,6 +598,11 @@ extern "C" int mc_model_check(mc_model *m, void *stream, uint64_t counters[8]) {
     HIP_TRY(hipMemsetAsync(m->dev.status, 0, sizeof host, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (counters) std::memcpy(counters, host, sizeof host);
+    if (host[MC_CNT_SCORE_TOO_LONG]) {
+        mc_set_error("%llu password(s) were longer than the max_len given to mc_score_words",
+                     (unsigned long long)host[MC_CNT_SCORE_TOO_LONG]);
+        return MC_ERR_ARG;
+    }
     if (host[MC_CNT_FAILED]) {
         mc_set_error("%llu sample(s) did not reach the end symbol within max_draws (or walked into a missing row); "
                      "the reference would not terminate on this model",
@@ -526,6 +683,48 @@ extern "C" int mc_score(mc_model *m, const uint32_t *syms, const uint64_t *off, 
     dim3 g((unsigned)(want < cap ? want : cap)), b(256);
     hipLaunchKernelGGL(k_score, g, b, 0, (hipStream_t)stream, m->dev, syms, (const unsigned long long *)off,
                        (unsigned long long)count, out_ml2p);
+    HIP_TRY(hipGetLastError());
+    return MC_OK;
+}
+
+static uint32_t words_lanes(const mc_model *m, uint64_t count) {
+    unsigned long long want = ((count + 255) / 256) * 256, cap = (unsigned long long)m->n_cu * 8 * 256;
+    return (uint32_t)(want < cap ? want : cap);
+}
+
+extern "C" size_t mc_score_words_workspace_bytes(const mc_model *m, uint64_t count, uint32_t max_len) {
+    if (!m || count == 0) return 0;
+    // deepest recursion: every symbol one character, plus the end symbol, plus the outermost call
+    return (size_t)words_lanes(m, count) * ((size_t)max_len + m->dev.end_text_len + 1) * sizeof(Frame);
+}
+
+extern "C" int mc_score_words(mc_model *m, const uint32_t *cps, const uint64_t *off, uint64_t count, uint32_t max_len,
+                              uint64_t iter_max, double *out_ml2p, uint64_t *out_split, uint32_t split_words,
+                              void *workspace, size_t workspace_bytes, void *stream) {
+    if (!m || (count && (!off || !out_ml2p || !workspace)) || (out_split && split_words == 0)) {
+        mc_set_error("mc_score_words: bad argument");
+        return MC_ERR_ARG;
+    }
+    if (count == 0) return MC_OK;
+    if (!m->has_text) {
+        mc_set_error("mc_score_words: the model was compiled without symbol text (mc_model_desc.sym_text_off)");
+        return MC_ERR_ARG;
+    }
+    if (m->dev.end_text_len == 0 || max_len > 65000u) {
+        mc_set_error("mc_score_words: empty end symbol or max_len above 65000");
+        return MC_ERR_ARG;
+    }
+    const size_t per_lane = ((size_t)max_len + m->dev.end_text_len + 1) * sizeof(Frame);
+    uint32_t lanes = words_lanes(m, count);
+    if ((size_t)lanes * per_lane > workspace_bytes) lanes = (uint32_t)((workspace_bytes / per_lane) / 256 * 256);
+    if (lanes == 0) {
+        mc_set_error("mc_score_words: workspace of %zu bytes cannot hold 256 DFS stacks of %zu bytes", workspace_bytes,
+                     per_lane);
+        return MC_ERR_WORKSPACE;
+    }
+    WordsArgs a{cps, (const unsigned long long *)off, count, iter_max, out_ml2p, (unsigned long long *)out_split,
+                (Frame *)workspace, split_words, max_len, lanes};
+    hipLaunchKernelGGL(k_score_words, dim3(lanes / 256), dim3(256), 0, (hipStream_t)stream, m->dev, a);
     HIP_TRY(hipGetLastError());
     return MC_OK;
 }

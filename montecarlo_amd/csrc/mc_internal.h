@@ -14,7 +14,8 @@ enum {
     MC_CNT_FAILED = 3,     // samples that hit max_draws or a missing row
     MC_CNT_SCORE_PROBES = 4,  // transition-hash slots read while scoring
     MC_CNT_SCORE_STEPS = 5,   // symbols consumed while scoring
-    MC_CNT_INDIRECT = 6       // draws whose bucket was not DIRECT (one more 16-byte record read)
+    MC_CNT_INDIRECT = 6,      // draws whose bucket was not DIRECT (one more 16-byte record read)
+    MC_CNT_SCORE_TOO_LONG = 7 // passwords longer than mc_score_words' max_len
 };
 
 struct mc_table {
@@ -34,6 +35,9 @@ struct mc_table {
     std::vector<mc_slot> trans;
     std::vector<mc_slot> ctxhash;
     std::vector<uint32_t> sym_chars;
+    std::vector<mc_slot> wordhash;        // empty when the descriptor had no symbol text
+    std::vector<uint32_t> sym_text_off, sym_text;
+    uint32_t max_word_len, start_sym;
 };
 
 void mc_set_error(const char *fmt, ...);

@@ -51,6 +51,15 @@ extern "C" uint64_t mc_ctx_hash(const uint32_t *units, uint32_t n) {
 
 uint64_t mc_trans_hash(uint64_t key) { return mix64(key + 0x9E3779B97F4A7C15ull); }
 
+// FNV-1a over code points, one step per character: the scoring kernel extends it character by
+// character as it tries longer and longer splits.
+extern "C" uint64_t mc_text_hash(const uint32_t *cps, uint32_t n) {
+    uint64_t h = 0xCBF29CE484222325ull;
+    for (uint32_t i = 0; i < n; ++i) h = (h ^ cps[i]) * 0x100000001B3ull;
+    if (h == ~0ull) h = ~0ull - 1;
+    return h;
+}
+
 namespace {
 
 uint64_t pow2ceil(uint64_t v) {
@@ -356,6 +365,36 @@ extern "C" int mc_table_compile(const mc_model_desc *d, mc_table **out) {
         }
     }
 
+    // ---- symbol text -> symbol id (the `left in self.words` lookup of _structures) ----------
+    t->max_word_len = 0;
+    // the start symbol as a transition id (contexts and transitions share ids except for V2)
+    t->start_sym = (d->kind != MC_KIND_V2 && d->n_start) ? d->start_units[0] : MC_NONE;
+    if (d->sym_text_off) {
+        t->sym_text_off.assign(d->sym_text_off, d->sym_text_off + d->n_sym + 1);
+        t->sym_text.assign(d->sym_text, d->sym_text + d->sym_text_off[d->n_sym]);
+        uint64_t wcap = pow2ceil(std::max<uint64_t>(16, 2ull * d->n_sym));
+        t->wordhash.assign(wcap, mc_slot{~0ull, 0, 0});
+        for (uint32_t s = 0; s < d->n_sym; ++s) {
+            const uint32_t a = d->sym_text_off[s], n = d->sym_text_off[s + 1] - a;
+            if (n == 0) continue;  // the empty string is never a split (index starts at 1)
+            t->max_word_len = std::max(t->max_word_len, n);
+            const uint64_t h = mc_text_hash(d->sym_text + a, n);
+            for (uint64_t i = h & (wcap - 1);; i = (i + 1) & (wcap - 1)) {
+                mc_slot &sl = t->wordhash[i];
+                if (sl.key == ~0ull) {
+                    sl = mc_slot{h, s, n};
+                    break;
+                }
+                const uint32_t b = d->sym_text_off[sl.val];
+                if (sl.key == h && sl.pad == n && std::memcmp(d->sym_text + b, d->sym_text + a, n * 4) == 0) {
+                    mc_set_error("symbols %u and %u have the same text", sl.val, s);
+                    delete t;
+                    return MC_ERR_TABLE;
+                }
+            }
+        }
+    }
+
     // ---- (row, symbol) -> entry hash ------------------------------------------------------
     uint64_t cap = pow2ceil(std::max<uint64_t>(16, 2ull * d->n_ent));
     t->trans.assign(cap, mc_slot{~0ull, 0, 0});
@@ -390,6 +429,9 @@ extern "C" int64_t mc_table_array(const mc_table *t, int what, void *dst, size_t
         case MC_ARR_DRAW: src = t->draw.data(); bytes = t->draw.size() * sizeof(mc_draw_rec); break;
         case MC_ARR_SPAY: src = t->spay.data(); bytes = t->spay.size() * sizeof(mc_draw_rec); break;
         case MC_ARR_RCUM: src = t->rcum.data(); bytes = t->rcum.size() * sizeof(double); break;
+        case MC_ARR_WORDHASH: src = t->wordhash.data(); bytes = t->wordhash.size() * sizeof(mc_slot); break;
+        case MC_ARR_SYMTEXTOFF: src = t->sym_text_off.data(); bytes = t->sym_text_off.size() * sizeof(uint32_t); break;
+        case MC_ARR_SYMTEXT: src = t->sym_text.data(); bytes = t->sym_text.size() * sizeof(uint32_t); break;
         case MC_ARR_CUM: src = t->cum.data(); bytes = t->cum.size() * sizeof(double); break;
         case MC_ARR_PAYLOAD: src = t->payload.data(); bytes = t->payload.size() * sizeof(mc_payload); break;
         case MC_ARR_TRANS: src = t->trans.data(); bytes = t->trans.size() * sizeof(mc_slot); break;
@@ -415,7 +457,7 @@ extern "C" int mc_table_info(const mc_table *t, uint64_t info[16]) {
     info[MC_INFO_DEVICE_BYTES] = mc_table_device_bytes(t);
     info[MC_INFO_MAX_ROW] = t->max_row;
     info[MC_INFO_KIND] = t->kind;
-    info[MC_INFO_MULTICHAR] = t->multichar ? 1 : 0;
+    info[MC_INFO_MULTICHAR] = (t->multichar ? 1 : 0) | ((uint64_t)t->max_word_len << 8);
     info[MC_INFO_START_DRAW] = t->start_draw | ((uint64_t)t->start_gbits << 32);
     info[MC_INFO_DIRECT_BUCKETS] = t->n_direct;
     info[MC_INFO_ONE_BUCKETS] = t->n_one;
@@ -430,5 +472,7 @@ size_t mc_table_device_bytes(const mc_table *t) {
            align256(t->spay.size() * sizeof(mc_draw_rec)) + align256(t->rcum.size() * sizeof(double)) +
            align256(t->payload.size() * sizeof(mc_payload)) +
            align256(t->trans.size() * sizeof(mc_slot)) + align256(t->ctxhash.size() * sizeof(mc_slot)) +
-           align256(t->sym_chars.size() * sizeof(uint32_t)) + align256(MC_STATUS_WORDS * sizeof(uint64_t));
+           align256(t->sym_chars.size() * sizeof(uint32_t)) + align256(t->wordhash.size() * sizeof(mc_slot)) +
+           align256(t->sym_text_off.size() * sizeof(uint32_t)) + align256(t->sym_text.size() * sizeof(uint32_t)) +
+           align256(MC_STATUS_WORDS * sizeof(uint64_t));
 }

@@ -16,7 +16,7 @@ from . import _native as nv
 from .tables import FlatTable
 
 DEFAULT_MAX_DRAWS = 1 << 16
-CNT_NAMES = ("draws", "cdf_probes", "restarts", "failed", "score_probes", "score_steps", "indirect_draws", "_7")
+CNT_NAMES = ("draws", "cdf_probes", "restarts", "failed", "score_probes", "score_steps", "indirect_draws", "score_too_long")
 
 
 def _require_gpu():
@@ -41,7 +41,7 @@ class DeviceModel:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and nv is not None and getattr(nv, "lib", None) is not None:   # (module may be gone at exit)
             nv.lib.mc_model_destroy(h)
             self._h = None
 
@@ -97,6 +97,24 @@ class DeviceModel:
             res = out if out is not None else torch.empty(count, dtype=torch.float64, device=self.tdev)
             nv.check(nv.lib.mc_score(self._h, _vp(d_syms), _vp(d_off), count, _vp(res), self._stream()))
         return res
+
+
+    def score_words(self, cps: np.ndarray, off: np.ndarray, max_len: int, iter_max: int, want_split: bool = True):
+        """calc_ml2p as the DFS over segmentations (any alphabet): (ml2p tensor, split masks or None)."""
+        count = len(off) - 1
+        with torch.cuda.device(self.tdev):
+            d_cps = torch.from_numpy(np.ascontiguousarray(cps, dtype=np.uint32).view(np.int32)).to(self.tdev)
+            d_off = torch.from_numpy(np.ascontiguousarray(off, dtype=np.uint64).view(np.int64)).to(self.tdev)
+            res = torch.empty(count, dtype=torch.float64, device=self.tdev)
+            words = (max_len + 1 + 63) // 64 if want_split else 0
+            split = torch.empty((count, words), dtype=torch.int64, device=self.tdev) if want_split else None
+            need = nv.lib.mc_score_words_workspace_bytes(self._h, count, max_len)
+            ws = torch.empty(max(need, 1), dtype=torch.uint8, device=self.tdev)
+            nv.check(nv.lib.mc_score_words(self._h, _vp(d_cps), _vp(d_off), count, max_len,
+                                           min(int(iter_max), 0xFFFFFFFFFFFFFFFF) if iter_max > 0 else 0, _vp(res),
+                                           _vp(split), words, _vp(ws), ws.numel(), self._stream()))
+            torch.cuda.current_stream(self.tdev).synchronize()      # inputs and workspace must outlive the kernel
+        return res, split
 
 
 class DeviceRank:

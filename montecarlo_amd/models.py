@@ -5,6 +5,8 @@ from __future__ import annotations
 
 from typing import List, Tuple
 
+import numpy as np
+
 from . import _native as nv
 from .tables import FlatTable
 
@@ -33,11 +35,36 @@ class TableBacked:
 
     def score_batch(self, pwds: List[str]):
         flat = self._flat
-        if flat.multichar:
-            raise NotImplementedError("scoring of multi-character (sub-word) alphabets is not built yet")
-        syms, off = flat.encode_chars(pwds)
-        ml2p = self._dev.score_ids(syms, off).cpu().numpy().tolist()
         end = self.end_chr
-        parts = [[c for c in p if c != end] if m < UNPARSEABLE else ([p] if p != end else [])
-                 for p, m in zip(pwds, ml2p)]
+        if not flat.multichar:
+            # single-character alphabets have exactly one parse: the lookup-chain kernel
+            syms, off = flat.encode_chars(pwds)
+            ml2p = self._dev.score_ids(syms, off).cpu().numpy().tolist()
+            parts = [[c for c in p if c != end] if m < UNPARSEABLE else ([p] if p != end else [])
+                     for p, m in zip(pwds, ml2p)]
+            return ml2p, parts
+        return self.score_batch_dfs(pwds)
+
+    def score_batch_dfs(self, pwds: List[str]):
+        """calc_ml2p through the DFS kernel (sub-word alphabets; valid for any alphabet)."""
+        if not pwds:
+            return [], []
+        cps, off, max_len = self._flat.encode_text(pwds)
+        iter_max = getattr(self, "max_iter", 10 ** 35)          # nwords_simulator.py:88 passes 1e35
+        res, split = self._dev.score_words(cps, off, max_len, iter_max)
+        self._dev.check()
+        ml2p = res.cpu().numpy().tolist()
+        masks = split.cpu().numpy().view(np.uint64)
+        end = self.end_chr
+        parts = []
+        for p, m, row in zip(pwds, ml2p, masks):
+            if not m < UNPARSEABLE:
+                parts.append([p] if p != end else [])       # component_list starts as [pwd] (:86)
+                continue
+            text, toks, prev = p + end, [], 0
+            for j in range(len(text)):
+                if (int(row[j >> 6]) >> (j & 63)) & 1:
+                    toks.append(text[prev:j + 1])
+                    prev = j + 1
+            parts.append([c for c in toks if c != end])
         return ml2p, parts

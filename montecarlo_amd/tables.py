@@ -112,6 +112,11 @@ class FlatTable:
             keep += [su_off, a_su]
             d.sym_unit_off, d.sym_units = _ptr(su_off, nv.u32p), _ptr(a_su, nv.u32p)
         d.sym_chars = _ptr(a_chars, nv.u32p)
+        text_off = np.zeros(len(symbols) + 1, dtype=np.uint32)
+        np.cumsum(a_chars, out=text_off[1:])
+        a_text = np.frombuffer("".join(symbols).encode("utf-32-le", "surrogatepass"), dtype="<u4").astype(np.uint32)
+        keep += [text_off, a_text]
+        d.sym_text_off, d.sym_text = _ptr(text_off, nv.u32p), _ptr(a_text, nv.u32p)
         d.start_units, d.n_start = _ptr(start_ids, nv.u32p), len(start_ids)
         d.end_sym, d.min_len, d.max_len, d.flags, d.guide_factor = end_sym, min_len, max_len, flags, guide_factor
         handle = C.c_void_p()
@@ -121,12 +126,13 @@ class FlatTable:
         info = (C.c_uint64 * 16)()
         nv.check(nv.lib.mc_table_info(self._h, info))
         self.info = list(info)
-        self.multichar = bool(self.info[nv.INFO_MULTICHAR])
+        self.multichar = bool(self.info[nv.INFO_MULTICHAR] & 1)
+        self.max_word_len = int(self.info[nv.INFO_MULTICHAR] >> 8)
         self._lut: Optional[np.ndarray] = None
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and nv is not None and getattr(nv, "lib", None) is not None:   # (module may be gone at exit)
             nv.lib.mc_table_free(h)
             self._h = None
 
@@ -138,7 +144,8 @@ class FlatTable:
     def array(self, what: int) -> np.ndarray:
         dt = {nv.ARR_STATE: STATE_DT, nv.ARR_DRAW: DRAW_DT, nv.ARR_CUM: np.dtype("<f8"),
               nv.ARR_PAYLOAD: PAYLOAD_DT, nv.ARR_TRANS: SLOT_DT, nv.ARR_CTXHASH: SLOT_DT,
-              nv.ARR_SYMCHARS: np.dtype("<u4"), nv.ARR_SPAY: DRAW_DT, nv.ARR_RCUM: np.dtype("<f8")}[what]
+              nv.ARR_SYMCHARS: np.dtype("<u4"), nv.ARR_SPAY: DRAW_DT, nv.ARR_RCUM: np.dtype("<f8"),
+              nv.ARR_WORDHASH: SLOT_DT, nv.ARR_SYMTEXTOFF: np.dtype("<u4"), nv.ARR_SYMTEXT: np.dtype("<u4")}[what]
         size = nv.check(nv.lib.mc_table_array(self._h, what, None, 0))
         out = np.empty(size // dt.itemsize, dtype=dt)
         nv.check(nv.lib.mc_table_array(self._h, what, out.ctypes.data_as(C.c_void_p), size))
@@ -159,6 +166,16 @@ class FlatTable:
         np.cumsum(lens, out=off[1:])
         cps = np.frombuffer("".join(pwds).encode("utf-32-le", "surrogatepass"), dtype="<u4")
         return self._lut[cps], off
+
+    @staticmethod
+    def encode_text(pwds: Iterable[str]):
+        """Passwords -> (code points, offsets) for mc_score_words."""
+        pwds = list(pwds)
+        lens = np.fromiter((len(p) for p in pwds), dtype=np.uint64, count=len(pwds))
+        off = np.zeros(len(pwds) + 1, dtype=np.uint64)
+        np.cumsum(lens, out=off[1:])
+        cps = np.frombuffer("".join(pwds).encode("utf-32-le", "surrogatepass"), dtype="<u4").astype(np.uint32)
+        return cps, off, int(lens.max()) if len(pwds) else 0
 
     def decode(self, syms: np.ndarray, lens: np.ndarray, drop: str = "") -> List[str]:
         """Symbol-id rows -> strings (``drop``: the start symbol, which the reference

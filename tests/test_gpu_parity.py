@@ -80,6 +80,40 @@ def test_subword_sampling(train_tab):
     device_samples(m, golden("backwords_thr3_tab.json"))
 
 
+def test_subword_scoring(train_tab, train_char):
+    """calc_ml2p for sub-word alphabets: the DFS kernel (every segmentation, minimum, iter_max)
+    against the reference's values and components (golden), through the plugin surface."""
+    m = NWordsMonteCarlo(synth.as_file(train_tab), n=3, splitter="\t")
+    device_scores(m, golden("nwords_n3_tab.json"))
+    m = BackWordsMonteCarlo(synth.as_file(train_tab), splitter="\t", threshold=3)
+    fx = golden("backwords_thr3_tab.json")
+    device_scores(m, fx)
+    assert m.calc_ml2p(fx["scores"][0][0]) == (fh(fx["scores"][0][1]), fx["scores"][0][2])
+    scored = m.parse_file(synth.as_file(golden_lines("test_tab.txt")), using_component=True)
+    want = {s[0]: (s[1], s[2]) for s in fx["scores"]}
+    assert all(isinstance(c, list) for c, _, _ in scored)
+    assert [x for _, _, x in scored] == sorted(x for _, _, x in scored)
+    for comps, _cnt, x in scored:
+        pwd = "".join(comps)
+        if pwd in want:
+            assert (hx(x), comps) == want[pwd]
+    m2 = BackWordsMonteCarlo(synth.as_file(train_tab), splitter="\t", threshold=3, max_iter=2)
+    device_scores(m2, golden("backwords_thr3_tab_maxiter2.json"))
+    # the DFS kernel on a single-character alphabet agrees with the lookup-chain kernel and the golden values
+    mc = BackWordsMonteCarlo(synth.as_file(train_char), splitter="", threshold=10)
+    fxc = golden("backwords_thr10_char.json")
+    pw = [s[0] for s in fxc["scores"]]
+    ml2p, parts = mc.score_batch_dfs(pw)
+    assert [hx(x) for x in ml2p] == [s[1] for s in fxc["scores"]]
+    assert parts == [s[2] for s in fxc["scores"]]
+    # a password longer than the declared bound is reported, not silently mis-scored
+    cps, off, max_len = mc._flat.encode_text(["abc", "x" * 40])
+    res, _ = mc._dev.score_words(cps, off, 10, 10 ** 35)
+    with pytest.raises(Exception, match="longer than the max_len"):
+        mc._dev.check()
+    assert np.isnan(res.cpu().numpy()[1])
+
+
 def test_secondary_and_v2(train_char, train_v2):
     fx = golden("secondary_thr4_char.json")
     cfg = {"start_chr": "\x03", "end_chr": "\x00", "threshold": 4}

@@ -68,6 +68,23 @@ def check_walk(fx, model, n_samples=150, n_scores=None, keep_len=False):
             ids, _ = flat.encode_chars([pwd])
             got = w.score(ids.tolist(), flat.end_sym, len(flat.symbols))
             assert hx(got) == want, repr(pwd)
+    if "scores" in fx:
+        check_dfs(fx, model, w, 60 if not flat.multichar else n_scores)
+
+
+def check_dfs(fx, model, w, n_scores=None, iter_max=None):
+    """The DFS walk (k_score_words' mirror) against the reference's calc_ml2p and components."""
+    end = model.end_chr
+    iter_max = iter_max if iter_max is not None else getattr(model, "max_iter", 10 ** 35)
+    for pwd, want, parts in fx["scores"][:n_scores]:
+        got, ends = w.score_words(pwd, end, iter_max)
+        assert hx(got) == want, repr(pwd)
+        text, toks, prev = pwd + end, [], 0
+        for e in ends:
+            toks.append(text[prev:e])
+            prev = e
+        toks = [c for c in toks if c != end] if got < 1022.0 else ([pwd] if pwd != end else [])
+        assert toks == parts, repr(pwd)
 
 
 @pytest.mark.parametrize("n", [2, 4])
@@ -99,6 +116,8 @@ def test_backwords_tab(train_tab):
     m = BackWordsMonteCarlo(synth.as_file(train_tab), splitter="\t", threshold=3)
     check_table(fx, m)
     check_walk(fx, m)
+    # --max-iter 2: the parse cap of the recursion (entry check only, callers finish their loops)
+    check_dfs(golden("backwords_thr3_tab_maxiter2.json"), m, CompiledWalker(m._flat), iter_max=2)
 
 
 def test_secondary(train_char):

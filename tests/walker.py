@@ -31,6 +31,10 @@ class CompiledWalker:
         self.trans = flat.array(nv.ARR_TRANS)
         self.sym_chars = flat.array(nv.ARR_SYMCHARS)
         self.start = flat.info[nv.INFO_START_STATE]
+        self.wordhash = flat.array(nv.ARR_WORDHASH)
+        self.sym_text_off = flat.array(nv.ARR_SYMTEXTOFF)
+        self.sym_text = flat.array(nv.ARR_SYMTEXT)
+        self.max_word_len = flat.max_word_len
         self.start_draw = flat.info[nv.INFO_START_DRAW] & 0xFFFFFFFF
         self.start_gbits = flat.info[nv.INFO_START_DRAW] >> 32
 
@@ -118,3 +122,62 @@ class CompiledWalker:
             acc += float(p["ml2p"])
             st = int(p["next"])
         return acc if acc < 1022.0 else 1022.0
+
+    def entry(self, state, s):
+        row = state
+        while row != NONE:
+            e = self.find(row, s)
+            if e != NONE:
+                return e
+            row = int(self.state[row]["parent"])
+        return NONE
+
+    def word(self, cps):
+        h = 0xCBF29CE484222325
+        for c in cps:
+            h = ((h ^ c) * 0x100000001B3) & MASK64
+        if h == MASK64:
+            h -= 1
+        mask = len(self.wordhash) - 1
+        q = h & mask
+        while True:
+            sl = self.wordhash[q]
+            if int(sl["key"]) == MASK64:
+                return NONE
+            if int(sl["key"]) == h and int(sl["pad"]) == len(cps):
+                a = int(self.sym_text_off[int(sl["val"])])
+                if list(self.sym_text[a:a + len(cps)]) == list(cps):
+                    return int(sl["val"])
+            q = (q + 1) & mask
+
+    # mirrors k_score_words: (ml2p, split end offsets of the best parse)
+    def score_words(self, text, end_text, iter_max, start_sym=NONE):
+        cps = [ord(c) for c in text + end_text]
+        total = len(cps)
+        best, best_ends, done = 1022.0, [], 0
+        stack = [[0.0, self.start, 0, 1]] if iter_max > 0 else []
+        while stack:
+            acc, state, pos, idx0 = stack[-1]
+            top = min(total - pos, self.max_word_len)
+            advanced = False
+            for idx in range(idx0, top + 1):
+                sym = self.word(cps[pos:pos + idx])
+                if sym == NONE or sym == start_sym:
+                    continue
+                e = self.entry(state, sym)
+                if e == NONE:
+                    continue
+                p = self.payload[e]
+                nacc = acc + float(p["ml2p"])
+                stack[-1][3] = idx + 1
+                if pos + idx == total:
+                    if best > nacc:
+                        best, best_ends = nacc, [f[2] + f[3] - 1 for f in stack]
+                    done += 1
+                if done < iter_max:
+                    stack.append([nacc, int(p["next"]), pos + idx, 1])
+                advanced = True
+                break
+            if not advanced:
+                stack.pop()
+        return best, best_ends

@@ -40,7 +40,9 @@ typedef enum mc_status {
 enum {
     MC_KIND_NGRAM = 1,   /* nwords_simulator.py:30-34: context = last `order` symbols (exact row required) */
     MC_KIND_BACKOFF = 2, /* backwords_simulator.py:28-41: longest suffix of the history that is a row */
-    MC_KIND_V2 = 3       /* nwords_simulator_v2.py:65-68: context = last `order` CHARACTERS; transitions are words */
+    MC_KIND_V2 = 3,      /* nwords_simulator_v2.py:65-68: context = last `order` CHARACTERS; transitions are words */
+    MC_KIND_BPE = 4      /* bpe_simulator.py:104-157: row 0 = the grammar (entry i = structure i), rows 1.. = the
+                          * terminal rows; every row has the one-unit context {row index}; start_units = {0} */
 };
 
 enum {
@@ -86,6 +88,17 @@ typedef struct mc_model_desc {
      * (nwords_simulator.py:42-45).  NULL: mc_score_words is unavailable for the model. */
     const uint32_t *sym_text_off; /* [n_sym+1] or NULL */
     const uint32_t *sym_text;
+    /* ---- MC_KIND_BPE only (NULL / 0 otherwise) ------------------------------------------------
+     * Structure i is the segments seg_off[i] .. seg_off[i+1]: seg_row[k] = the row of terminals
+     * (tag, t_len) (MC_NONE when the model has none: the reference raises KeyError there), seg_len[k] =
+     * t_len.  calc_ml2p's candidate index (count_luds, bpe_simulator.py:45-101): label j is the units
+     * lab_units[lab_off[j] .. lab_off[j+1]) (unit = class << 24 | run length; class 0..3 = L U D S, luds
+     * :17-40) with candidate structures lab_cand[lab_cand_off[j] .. lab_cand_off[j+1]); not_parsed[k] is
+     * the structures np_cand[np_off[k] .. np_off[k+1]) of total length np_len[k]. */
+    const uint32_t *seg_off, *seg_row, *seg_len;
+    uint32_t n_labels, n_np;
+    const uint32_t *lab_off, *lab_units, *lab_cand_off, *lab_cand;
+    const uint32_t *np_len, *np_off, *np_cand;
 } mc_model_desc;
 
 typedef struct mc_table mc_table; /* compiled table, host memory */
@@ -202,7 +215,10 @@ int mc_model_check(mc_model *m, void *stream, uint64_t counters[8]);
  * depend on launch geometry.  Outputs (device): out_ml2p[count]; optional out_len[count]
  * (symbols emitted), out_draws[count] (uniforms consumed, restarts included), and
  * out_syms[count*sym_stride] (symbol ids; samples longer than sym_stride are truncated
- * there, out_len still reports the full length). */
+ * there, out_len still reports the full length).  For MC_KIND_BPE the walk is BpePcfgSim.sample1
+ * (bpe_simulator.py:105-116): one structure draw, then one terminal draw per segment, no
+ * rejection; out_syms then holds the ENTRY index of every terminal drawn and out_len the number
+ * of segments. */
 int mc_sample(mc_model *m, uint64_t first_id, uint64_t count, uint64_t seed, uint32_t max_draws,
               double *out_ml2p, uint32_t *out_len, uint32_t *out_draws, uint32_t *out_syms,
               uint32_t sym_stride, void *stream);
@@ -238,6 +254,15 @@ size_t mc_score_words_workspace_bytes(const mc_model *m, uint64_t count, uint32_
 int mc_score_words(mc_model *m, const uint32_t *cps, const uint64_t *off, uint64_t count, uint32_t max_len,
                    uint64_t iter_max, double *out_ml2p, uint64_t *out_split, uint32_t split_words,
                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- BPE-PCFG scoring: BpePcfgSim.calc_ml2p over a batch (bpe_simulator.py:118-150).  cls[] holds
+ * luds' character class of every code point (0..3 = L U D S), decided on the host with Python's own
+ * str.isalpha/isupper/isdigit.  out_ml2p[t] = min over the candidate structures of
+ * grammar -log2 p + sum of terminal -log2 p (left to right), 1022.0 when there is none.  (The
+ * reference's `break` on a candidate whose grammar value equals 1022.0 depends on set iteration
+ * order and is not reproduced; no model of finite probabilities reaches it.) */
+int mc_score_bpe(mc_model *m, const uint32_t *cps, const uint8_t *cls, const uint64_t *off, uint64_t count,
+                 double *out_ml2p, void *stream);
 
 /* ---- rank estimation: MonteCarloLib.__init__ (lib4mc/MonteCarloLib.py:10-28): sort the
  * sampled -log2 p ascending, positions = cumsum(2^(key - log2 n_global)).  keys_sorted and

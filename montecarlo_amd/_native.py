@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmi355mc.so")
 
 MC_NONE = 0xFFFFFFFF
-KIND_NGRAM, KIND_BACKOFF, KIND_V2 = 1, 2, 3
+KIND_NGRAM, KIND_BACKOFF, KIND_V2, KIND_BPE = 1, 2, 3, 4
 FLAG_KEEP_LEN_ON_RESTART = 1
 (ARR_STATE, ARR_DRAW, ARR_CUM, ARR_PAYLOAD, ARR_TRANS, ARR_CTXHASH, ARR_SYMCHARS, ARR_SPAY, ARR_RCUM, ARR_WORDHASH,
  ARR_SYMTEXTOFF, ARR_SYMTEXT) = range(12)
@@ -43,6 +43,10 @@ class ModelDesc(C.Structure):
         ("end_sym", C.c_uint32), ("min_len", C.c_uint32), ("max_len", C.c_uint32), ("flags", C.c_uint32),
         ("guide_factor", C.c_uint32),
         ("sym_text_off", u32p), ("sym_text", u32p),
+        ("seg_off", u32p), ("seg_row", u32p), ("seg_len", u32p),
+        ("n_labels", C.c_uint32), ("n_np", C.c_uint32),
+        ("lab_off", u32p), ("lab_units", u32p), ("lab_cand_off", u32p), ("lab_cand", u32p),
+        ("np_len", u32p), ("np_off", u32p), ("np_cand", u32p),
     ]
 
 
@@ -77,6 +81,7 @@ def _load() -> C.CDLL:
         "mc_score_words_workspace_bytes": (C.c_size_t, [vp, C.c_uint64, C.c_uint32]),
         "mc_score_words": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint64, vp, vp, C.c_uint32, vp,
                                      C.c_size_t, vp]),
+        "mc_score_bpe": (C.c_int, [vp, vp, vp, vp, C.c_uint64, vp, vp]),
         "mc_rank_workspace_bytes": (C.c_size_t, [C.c_uint64]),
         "mc_rank_build": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, vp, vp, C.c_size_t, vp]),
         "mc_rank_query": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp]),
@@ -89,7 +94,7 @@ def _load() -> C.CDLL:
 
 lib = _load()
 EXPORTS = ["mc_abi_version", "mc_last_error", "mc_table_compile", "mc_table_free", "mc_table_array", "mc_table_info",
-           "mc_ctx_hash", "mc_text_hash", "mc_score_words_workspace_bytes", "mc_score_words", "mc_model_upload", "mc_model_destroy", "mc_model_check", "mc_sample", "mc_sample_injected",
+           "mc_ctx_hash", "mc_text_hash", "mc_score_words_workspace_bytes", "mc_score_words", "mc_score_bpe", "mc_model_upload", "mc_model_destroy", "mc_model_check", "mc_sample", "mc_sample_injected",
            "mc_score", "mc_rank_workspace_bytes", "mc_rank_build", "mc_rank_query"]
 
 

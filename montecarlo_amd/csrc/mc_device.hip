@@ -65,6 +65,12 @@ struct DevModel {
     uint32_t start_draw, start_gbits;
     unsigned long long word_mask;
     uint32_t max_word_len, start_sym, end_text_off, end_text_len;
+    // MC_KIND_BPE
+    const uint32_t *seg_off, *seg_row, *seg_len;
+    const Slot *labhash;
+    const uint32_t *lab_off, *lab_units, *lab_cand_off, *lab_cand, *np_len, *np_off, *np_cand;
+    unsigned long long lab_mask;
+    uint32_t n_np, kind;
 };
 
 struct SampleArgs {
@@ -499,6 +505,228 @@ __global__ void __launch_bounds__(256) k_score_words(DevModel m, WordsArgs a) {
     }
 }
 
+// ---- BPE-PCFG (bpe_simulator.py:104-157) -----------------------------------------------------------
+// One draw of the bucketed table for the row whose buckets start at goff (see k_sample).
+template <bool INJECT>
+__device__ __forceinline__ DrawRec draw_one(const DevModel &m, uint32_t goff, uint32_t gbits, unsigned long long m53,
+                                            double rin, unsigned int &c_probes, unsigned int &c_indirect) {
+    uint32_t k;
+    if (INJECT) {
+        const double kk = rin * (double)(1u << gbits);
+        const uint32_t kmax = (1u << gbits) - 1u;
+        k = kk >= (double)kmax ? kmax : (kk > 0.0 ? (uint32_t)kk : 0u);
+    } else {
+        k = (uint32_t)(m53 >> (53u - gbits));
+    }
+    DrawRec q = ((const DrawRec *)m.draw)[goff + k];
+    const uint32_t type = MC_DRAW_TYPE(q.w3);
+    if (type != MC_DRAW_DIRECT) {
+        const double r = INJECT ? rin : (double)m53 * 0x1.0p-53;
+        uint32_t idx = q.w2;
+        if (type == MC_DRAW_ONE) {
+            idx += (r >= rec_f64(q)) ? 1u : 0u;
+            ++c_probes;
+        } else {
+            uint32_t lo = 0, hi = q.w0;
+            const double *T = m.rcum + q.w2;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (T[mid] > r) hi = mid; else lo = mid + 1;
+                ++c_probes;
+            }
+            idx += lo;
+        }
+        q = ((const DrawRec *)m.spay)[idx];
+        ++c_indirect;
+    }
+    return q;
+}
+
+// BpePcfgSim.sample1 (bpe_simulator.py:105-116): draw a structure from the grammar row, then one
+// terminal per segment from the row of (tag, t_len); ml2p = the precomputed -log2 p added in draw
+// order; no rejection.  One lane per sample; draw k of sample i uses uniform (seed, i, k).
+template <bool INJECT>
+__global__ void __launch_bounds__(256) k_sample_bpe(DevModel m, SampleArgs a) {
+    unsigned int c_draws = 0, c_probes = 0, c_fail = 0, c_indirect = 0;
+    const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
+    const double nan = __longlong_as_double(0x7FF8000000000000ll);
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.count;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned long long sid = a.first_id + i;
+        uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, draw = 0;
+        auto next_uniform = [&](unsigned long long &m53, double &r) {
+            if (INJECT) {
+                r = a.uniforms[i * a.max_draws + draw];
+                m53 = 0;
+            } else {
+                if ((draw & 1u) == 0)
+                    philox4x32_10((uint32_t)sid, (uint32_t)(sid >> 32), draw >> 1, 0u, k0, k1, o0, o1, o2, o3);
+                const uint32_t wa = (draw & 1u) ? o2 : o0, wb = (draw & 1u) ? o3 : o1;
+                m53 = ((unsigned long long)(wa >> 5) << 26) | (unsigned long long)(wb >> 6);
+                r = 0.0;
+            }
+            ++draw;
+        };
+        unsigned long long m53;
+        double r;
+        next_uniform(m53, r);
+        DrawRec q = draw_one<INJECT>(m, m.start_draw, m.start_gbits, m53, r, c_probes, c_indirect);
+        double acc = rec_f64(q);
+        const uint32_t st = q.w2;  // entry of row 0 = structure index
+        const uint32_t s0 = m.seg_off[st], s1 = m.seg_off[st + 1];
+        bool ok = true;
+        for (uint32_t k = s0; k < s1; ++k) {
+            const uint32_t row = m.seg_row[k];
+            if (row == MC_NONE || draw >= a.max_draws) {  // self.__terminals[tag_len] raises KeyError (:112)
+                ok = false;
+                break;
+            }
+            const StateRec rec = m.state[row];
+            next_uniform(m53, r);
+            q = draw_one<INJECT>(m, rec.guide_off, rec.gbits, m53, r, c_probes, c_indirect);
+            acc += rec_f64(q);
+            if (a.out_syms && k - s0 < a.sym_stride) a.out_syms[i * a.sym_stride + (k - s0)] = q.w2;
+        }
+        c_draws += draw;
+        if (!ok) ++c_fail;
+        a.out_ml2p[i] = ok ? acc : nan;
+        if (a.out_len) a.out_len[i] = s1 - s0;
+        if (a.out_draws) a.out_draws[i] = draw;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        c_draws += __shfl_down(c_draws, o);
+        c_probes += __shfl_down(c_probes, o);
+        c_fail += __shfl_down(c_fail, o);
+        c_indirect += __shfl_down(c_indirect, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&m.status[MC_CNT_DRAWS], (unsigned long long)c_draws);
+        atomicAdd(&m.status[MC_CNT_PROBES], (unsigned long long)c_probes);
+        atomicAdd(&m.status[MC_CNT_INDIRECT], (unsigned long long)c_indirect);
+        if (c_fail) atomicAdd(&m.status[MC_CNT_FAILED], (unsigned long long)c_fail);
+    }
+}
+
+// BpePcfgSim.calc_ml2p (bpe_simulator.py:118-150), one lane per password.
+__global__ void __launch_bounds__(256) k_score_bpe(DevModel m, const uint32_t *__restrict__ cps,
+                                                   const uint8_t *__restrict__ cls,
+                                                   const unsigned long long *__restrict__ off, unsigned long long count,
+                                                   double *__restrict__ out) {
+    unsigned int c_probe = 0, c_step = 0;
+    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < count;
+         t += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned long long p0 = off[t];
+        const uint32_t len = (uint32_t)(off[t + 1] - p0);
+        // luds (:17-40): runs of equal class; hashed as the label index hashes its units (mc_ctx_hash).
+        // luds of "" is ((" ", 0),): no structure has that label, and no structure has total length 0.
+        uint32_t n_units = 0;
+        for (uint32_t j = 0; j < len; ++j)
+            if (j == 0 || cls[p0 + j] != cls[p0 + j - 1]) ++n_units;
+        unsigned long long h = 0x9E3779B97F4A7C15ull ^ ((unsigned long long)n_units << 32);
+        for (uint32_t j = 0; j < len;) {
+            uint32_t e = j + 1;
+            while (e < len && cls[p0 + e] == cls[p0 + j]) ++e;
+            const uint32_t unit = ((uint32_t)cls[p0 + j] << 24) | (e - j);
+            h = mix64(h ^ ((unsigned long long)unit + 0x632BE59BD9B4E019ull));
+            j = e;
+        }
+        if (h == ~0ull) h = ~0ull - 1;
+        const uint32_t *cand = nullptr;
+        uint32_t n_cand = 0;
+        if (len > 0 && m.lab_mask) {
+            for (unsigned long long q = h & m.lab_mask;; q = (q + 1) & m.lab_mask) {
+                const Slot sl = m.labhash[q];
+                if (sl.key == ~0ull) break;
+                if (sl.key == h && sl.pad == n_units) {
+                    const uint32_t *u = m.lab_units + m.lab_off[sl.val];
+                    bool same = true;
+                    uint32_t ui = 0;
+                    for (uint32_t j = 0; j < len && same;) {
+                        uint32_t e = j + 1;
+                        while (e < len && cls[p0 + e] == cls[p0 + j]) ++e;
+                        same = u[ui++] == (((uint32_t)cls[p0 + j] << 24) | (e - j));
+                        j = e;
+                    }
+                    if (same) {
+                        cand = m.lab_cand + m.lab_cand_off[sl.val];
+                        n_cand = m.lab_cand_off[sl.val + 1] - m.lab_cand_off[sl.val];
+                        break;
+                    }
+                }
+            }
+        }
+        if (n_cand == 0)  // :122-125: fall back to the mixed-tag structures of the same total length
+            for (uint32_t k = 0; k < m.n_np; ++k)
+                if (m.np_len[k] == len) {
+                    cand = m.np_cand + m.np_off[k];
+                    n_cand = m.np_off[k + 1] - m.np_off[k];
+                    break;
+                }
+        double best = 1022.0;
+        for (uint32_t c = 0; c < n_cand; ++c) {
+            const uint32_t st = cand[c];
+            double p = m.payload[st].ml2p;  // grammars[candidate]: row 0 starts at entry 0
+            uint32_t start = 0;
+            bool ok = true;
+            for (uint32_t k = m.seg_off[st]; k < m.seg_off[st + 1]; ++k) {
+                const uint32_t row = m.seg_row[k], tl = m.seg_len[k];
+                // replacement = pwd[start:start + t_len]  (slicing clamps at the end of the string)
+                const uint32_t b = start < len ? start : len, e = start + tl < len ? start + tl : len;
+                start += tl;
+                uint32_t sym = MC_NONE;
+                if (row != MC_NONE && e > b) {
+                    unsigned long long hh = 0xCBF29CE484222325ull;
+                    for (uint32_t j = b; j < e; ++j) hh = (hh ^ cps[p0 + j]) * 0x100000001B3ull;
+                    if (hh == ~0ull) hh = ~0ull - 1;
+                    for (unsigned long long q = hh & m.word_mask;; q = (q + 1) & m.word_mask) {
+                        const Slot sl = m.wordhash[q];
+                        if (sl.key == ~0ull) break;
+                        if (sl.key == hh && sl.pad == e - b) {
+                            const uint32_t *txt = m.sym_text + m.sym_text_off[sl.val];
+                            bool same = true;
+                            for (uint32_t j = 0; j < e - b; ++j) same = same && txt[j] == cps[p0 + b + j];
+                            if (same) {
+                                sym = sl.val;
+                                break;
+                            }
+                        }
+                    }
+                }
+                uint32_t ent = MC_NONE;
+                if (sym != MC_NONE) {
+                    const unsigned long long key = ((unsigned long long)row << 32) | sym;
+                    for (unsigned long long q = mix64(key + 0x9E3779B97F4A7C15ull) & m.trans_mask;;
+                         q = (q + 1) & m.trans_mask) {
+                        const Slot sl = m.trans[q];
+                        ++c_probe;
+                        if (sl.key == key) {
+                            ent = sl.val;
+                            break;
+                        }
+                        if (sl.key == ~0ull) break;
+                    }
+                }
+                if (ent == MC_NONE) {  // replacement not in terminal (:139-141)
+                    ok = false;
+                    break;
+                }
+                p += m.payload[ent].ml2p;
+                ++c_step;
+            }
+            if (ok && p < 1022.0 && p < best) best = p;
+        }
+        out[t] = best;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        c_probe += __shfl_down(c_probe, o);
+        c_step += __shfl_down(c_step, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&m.status[MC_CNT_SCORE_PROBES], (unsigned long long)c_probe);
+        atomicAdd(&m.status[MC_CNT_SCORE_STEPS], (unsigned long long)c_step);
+    }
+}
+
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 }  // namespace
@@ -560,6 +788,20 @@ extern "C" int mc_model_upload(const mc_table *t, int device, mc_model **out) {
     d.start_sym = t->start_sym;
     d.end_text_off = t->sym_text_off.empty() ? 0 : t->sym_text_off[t->end_sym];
     d.end_text_len = t->sym_text_off.empty() ? 0 : t->sym_text_off[t->end_sym + 1] - t->sym_text_off[t->end_sym];
+    d.seg_off = (const uint32_t *)put(t->seg_off.data(), t->seg_off.size() * 4);
+    d.seg_row = (const uint32_t *)put(t->seg_row.data(), t->seg_row.size() * 4);
+    d.seg_len = (const uint32_t *)put(t->seg_len.data(), t->seg_len.size() * 4);
+    d.labhash = (const Slot *)put(t->labhash.data(), t->labhash.size() * sizeof(mc_slot));
+    d.lab_off = (const uint32_t *)put(t->lab_off.data(), t->lab_off.size() * 4);
+    d.lab_units = (const uint32_t *)put(t->lab_units.data(), t->lab_units.size() * 4);
+    d.lab_cand_off = (const uint32_t *)put(t->lab_cand_off.data(), t->lab_cand_off.size() * 4);
+    d.lab_cand = (const uint32_t *)put(t->lab_cand.data(), t->lab_cand.size() * 4);
+    d.np_len = (const uint32_t *)put(t->np_len.data(), t->np_len.size() * 4);
+    d.np_off = (const uint32_t *)put(t->np_off.data(), t->np_off.size() * 4);
+    d.np_cand = (const uint32_t *)put(t->np_cand.data(), t->np_cand.size() * 4);
+    d.lab_mask = t->labhash.empty() ? 0 : t->labhash.size() - 1;
+    d.n_np = (uint32_t)t->np_len.size();
+    d.kind = t->kind;
     d.status = (unsigned long long *)p;
     HIP_TRY(hipMemset(d.status, 0, MC_STATUS_WORDS * sizeof(uint64_t)));
     HIP_TRY(hipDeviceSynchronize());
@@ -618,6 +860,14 @@ static int launch_sample(mc_model *m, bool inject, const SampleArgs &a, hipStrea
         mc_set_error("the start context has no row (the reference exits in pick_expand, ProbLib.py:32-36)");
         return MC_ERR_TABLE;
     }
+    if (m->dev.kind == MC_KIND_BPE) {
+        unsigned long long want = (a.count + 255) / 256, cap = (unsigned long long)m->n_cu * 16;
+        dim3 g((unsigned)(want < cap ? want : cap)), b(256);
+        if (inject) hipLaunchKernelGGL(k_sample_bpe<true>, g, b, 0, s, m->dev, a);
+        else hipLaunchKernelGGL(k_sample_bpe<false>, g, b, 0, s, m->dev, a);
+        HIP_TRY(hipGetLastError());
+        return MC_OK;
+    }
     // Workgroups of 256 lanes; 16 per CU, of which 7-8 are resident at a time: a workgroup owns a
     // contiguous range of sample ids, and the second half of the grid evens out the ranges whose
     // strings came out long (measured: 16 per CU 12 % faster than 8, 64 slower again).  Two chains
@@ -675,8 +925,9 @@ extern "C" int mc_score(mc_model *m, const uint32_t *syms, const uint64_t *off, 
         return MC_ERR_ARG;
     }
     if (count == 0) return MC_OK;
-    if (m->multichar) {
-        mc_set_error("mc_score walks single-character alphabets only; this model has multi-character symbols");
+    if (m->multichar || m->dev.kind == MC_KIND_BPE || m->dev.kind == MC_KIND_V2) {
+        mc_set_error("mc_score walks single-character n-gram / backoff alphabets only (sub-word alphabets: "
+                     "mc_score_words; BPE-PCFG: mc_score_bpe)");
         return MC_ERR_ARG;
     }
     unsigned long long want = (count + 255) / 256, cap = (unsigned long long)m->n_cu * 8;
@@ -706,8 +957,9 @@ extern "C" int mc_score_words(mc_model *m, const uint32_t *cps, const uint64_t *
         return MC_ERR_ARG;
     }
     if (count == 0) return MC_OK;
-    if (!m->has_text) {
-        mc_set_error("mc_score_words: the model was compiled without symbol text (mc_model_desc.sym_text_off)");
+    if (!m->has_text || (m->dev.kind != MC_KIND_NGRAM && m->dev.kind != MC_KIND_BACKOFF)) {
+        mc_set_error("mc_score_words: needs an n-gram / backoff model compiled with symbol text "
+                     "(mc_model_desc.sym_text_off)");
         return MC_ERR_ARG;
     }
     if (m->dev.end_text_len == 0 || max_len > 65000u) {
@@ -725,6 +977,25 @@ extern "C" int mc_score_words(mc_model *m, const uint32_t *cps, const uint64_t *
     WordsArgs a{cps, (const unsigned long long *)off, count, iter_max, out_ml2p, (unsigned long long *)out_split,
                 (Frame *)workspace, split_words, max_len, lanes};
     hipLaunchKernelGGL(k_score_words, dim3(lanes / 256), dim3(256), 0, (hipStream_t)stream, m->dev, a);
+    HIP_TRY(hipGetLastError());
+    return MC_OK;
+}
+
+extern "C" int mc_score_bpe(mc_model *m, const uint32_t *cps, const uint8_t *cls, const uint64_t *off, uint64_t count,
+                            double *out_ml2p, void *stream) {
+    if (!m || (count && (!off || !out_ml2p))) {
+        mc_set_error("mc_score_bpe: bad argument");
+        return MC_ERR_ARG;
+    }
+    if (count == 0) return MC_OK;
+    if (m->dev.kind != MC_KIND_BPE) {
+        mc_set_error("mc_score_bpe: not a BPE-PCFG model");
+        return MC_ERR_ARG;
+    }
+    unsigned long long want = (count + 255) / 256, cap = (unsigned long long)m->n_cu * 8;
+    dim3 g((unsigned)(want < cap ? want : cap)), b(256);
+    hipLaunchKernelGGL(k_score_bpe, g, b, 0, (hipStream_t)stream, m->dev, cps, cls, (const unsigned long long *)off,
+                       (unsigned long long)count, out_ml2p);
     HIP_TRY(hipGetLastError());
     return MC_OK;
 }

@@ -38,6 +38,10 @@ struct mc_table {
     std::vector<mc_slot> wordhash;        // empty when the descriptor had no symbol text
     std::vector<uint32_t> sym_text_off, sym_text;
     uint32_t max_word_len, start_sym;
+    // MC_KIND_BPE
+    std::vector<uint32_t> seg_off, seg_row, seg_len;
+    std::vector<mc_slot> labhash;  // key = mc_ctx_hash(label units), val = label index
+    std::vector<uint32_t> lab_off, lab_units, lab_cand_off, lab_cand, np_len, np_off, np_cand;
 };
 
 void mc_set_error(const char *fmt, ...);

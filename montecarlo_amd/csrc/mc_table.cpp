@@ -140,7 +140,7 @@ extern "C" int mc_table_compile(const mc_model_desc *d, mc_table **out) {
         return MC_ERR_ARG;
     }
     *out = nullptr;
-    if (d->kind != MC_KIND_NGRAM && d->kind != MC_KIND_BACKOFF && d->kind != MC_KIND_V2) {
+    if (d->kind != MC_KIND_NGRAM && d->kind != MC_KIND_BACKOFF && d->kind != MC_KIND_V2 && d->kind != MC_KIND_BPE) {
         mc_set_error("unknown model kind %u", d->kind);
         return MC_ERR_ARG;
     }
@@ -155,7 +155,33 @@ extern "C" int mc_table_compile(const mc_model_desc *d, mc_table **out) {
                      (unsigned long long)d->n_ent, d->n_sym, d->end_sym);
         return MC_ERR_ARG;
     }
-    if (d->kind != MC_KIND_BACKOFF && d->order == 0) {
+    if (d->kind == MC_KIND_BPE) {
+        const uint64_t n_struct = d->row_off[1];
+        if (!d->seg_off || !d->seg_row || !d->seg_len || !d->sym_text_off || (d->n_labels && (!d->lab_off ||
+            !d->lab_units || !d->lab_cand_off || !d->lab_cand)) || (d->n_np && (!d->np_len || !d->np_off || !d->np_cand))) {
+            mc_set_error("MC_KIND_BPE needs seg_*, sym_text_* and the label / not_parsed arrays");
+            return MC_ERR_ARG;
+        }
+        for (uint64_t i = 0; i < n_struct; ++i)
+            for (uint32_t k = d->seg_off[i]; k < d->seg_off[i + 1]; ++k)
+                if (d->seg_row[k] != MC_NONE && (d->seg_row[k] == 0 || d->seg_row[k] >= d->n_ctx)) {
+                    mc_set_error("structure %llu: segment row %u out of range", (unsigned long long)i, d->seg_row[k]);
+                    return MC_ERR_ARG;
+                }
+        for (uint32_t j = 0; j < d->n_labels; ++j)
+            for (uint32_t k = d->lab_cand_off[j]; k < d->lab_cand_off[j + 1]; ++k)
+                if (d->lab_cand[k] >= n_struct) {
+                    mc_set_error("label %u: candidate %u is not a structure", j, d->lab_cand[k]);
+                    return MC_ERR_ARG;
+                }
+        for (uint32_t j = 0; j < d->n_np; ++j)
+            for (uint32_t k = d->np_off[j]; k < d->np_off[j + 1]; ++k)
+                if (d->np_cand[k] >= n_struct) {
+                    mc_set_error("not_parsed %u: candidate %u is not a structure", j, d->np_cand[k]);
+                    return MC_ERR_ARG;
+                }
+    }
+    if (d->kind != MC_KIND_BACKOFF && d->kind != MC_KIND_BPE && d->order == 0) {
         mc_set_error("fixed-order models need order >= 1 (n >= 2)");
         return MC_ERR_ARG;
     }
@@ -203,8 +229,10 @@ extern "C" int mc_table_compile(const mc_model_desc *d, mc_table **out) {
         }
 
     const bool backoff = d->kind == MC_KIND_BACKOFF;
+    const bool bpe = d->kind == MC_KIND_BPE;
     // the row that applies to a history `u[0..n)`, by the model's own context rule
     auto state_of = [&](const uint32_t *u, uint32_t n) -> uint32_t {
+        if (bpe) return n == 1 ? idx.find(u, 1) : MC_NONE;
         if (backoff) {
             for (uint32_t i = 0; i <= n; ++i) {  // longest suffix first, the empty context last
                 uint32_t r = idx.find(u + i, n - i);
@@ -305,7 +333,7 @@ extern "C" int mc_table_compile(const mc_model_desc *d, mc_table **out) {
             }
             mc_payload &p = t->payload[e];
             p.ml2p = d->ent_ml2p[e];
-            p.next = state_of(seq.data(), (uint32_t)seq.size());
+            p.next = bpe ? MC_NONE : state_of(seq.data(), (uint32_t)seq.size());
             p.sym = s | (s == d->end_sym ? 0x80000000u : 0u);
         }
     }
@@ -335,7 +363,9 @@ extern "C" int mc_table_compile(const mc_model_desc *d, mc_table **out) {
             std::memcpy(&q.w[0], &p.ml2p, sizeof(double));
             uint32_t nb = 0;
             q.w[2] = MC_NONE;
-            if (p.next != MC_NONE) {
+            if (bpe) {
+                q.w[2] = (uint32_t)(e0 + j);  // which row comes next depends on the structure: keep the entry
+            } else if (p.next != MC_NONE) {
                 q.w[2] = t->state[p.next].guide_off;
                 nb = t->state[p.next].gbits;
             }
@@ -388,6 +418,42 @@ extern "C" int mc_table_compile(const mc_model_desc *d, mc_table **out) {
                 const uint32_t b = d->sym_text_off[sl.val];
                 if (sl.key == h && sl.pad == n && std::memcmp(d->sym_text + b, d->sym_text + a, n * 4) == 0) {
                     mc_set_error("symbols %u and %u have the same text", sl.val, s);
+                    delete t;
+                    return MC_ERR_TABLE;
+                }
+            }
+        }
+    }
+
+    if (bpe) {
+        const uint32_t n_struct = (uint32_t)d->row_off[1];
+        t->seg_off.assign(d->seg_off, d->seg_off + n_struct + 1);
+        t->seg_row.assign(d->seg_row, d->seg_row + d->seg_off[n_struct]);
+        t->seg_len.assign(d->seg_len, d->seg_len + d->seg_off[n_struct]);
+        t->lab_off.assign(d->lab_off, d->lab_off + (d->n_labels ? d->n_labels + 1 : 0));
+        t->lab_cand_off.assign(d->lab_cand_off, d->lab_cand_off + (d->n_labels ? d->n_labels + 1 : 0));
+        if (d->n_labels) {
+            t->lab_units.assign(d->lab_units, d->lab_units + d->lab_off[d->n_labels]);
+            t->lab_cand.assign(d->lab_cand, d->lab_cand + d->lab_cand_off[d->n_labels]);
+        }
+        t->np_len.assign(d->np_len, d->np_len + d->n_np);
+        t->np_off.assign(d->np_off, d->np_off + (d->n_np ? d->n_np + 1 : 0));
+        if (d->n_np) t->np_cand.assign(d->np_cand, d->np_cand + d->np_off[d->n_np]);
+        uint64_t lcap = pow2ceil(std::max<uint64_t>(16, 2ull * d->n_labels));
+        t->labhash.assign(lcap, mc_slot{~0ull, 0, 0});
+        for (uint32_t j = 0; j < d->n_labels; ++j) {
+            const uint32_t a = d->lab_off[j], n = d->lab_off[j + 1] - a;
+            const uint64_t h = mc_ctx_hash(d->lab_units + a, n);
+            for (uint64_t i = h & (lcap - 1);; i = (i + 1) & (lcap - 1)) {
+                mc_slot &sl = t->labhash[i];
+                if (sl.key == ~0ull) {
+                    sl = mc_slot{h, j, n};
+                    break;
+                }
+                // equal hashes are told apart by the stored units on the device; equal labels are an error
+                const uint32_t b = d->lab_off[sl.val];
+                if (sl.key == h && sl.pad == n && std::memcmp(d->lab_units + b, d->lab_units + a, n * 4) == 0) {
+                    mc_set_error("labels %u and %u are the same", sl.val, j);
                     delete t;
                     return MC_ERR_TABLE;
                 }
@@ -474,5 +540,9 @@ size_t mc_table_device_bytes(const mc_table *t) {
            align256(t->trans.size() * sizeof(mc_slot)) + align256(t->ctxhash.size() * sizeof(mc_slot)) +
            align256(t->sym_chars.size() * sizeof(uint32_t)) + align256(t->wordhash.size() * sizeof(mc_slot)) +
            align256(t->sym_text_off.size() * sizeof(uint32_t)) + align256(t->sym_text.size() * sizeof(uint32_t)) +
-           align256(MC_STATUS_WORDS * sizeof(uint64_t));
+           align256(MC_STATUS_WORDS * sizeof(uint64_t)) +
+           align256(t->seg_off.size() * 4) + align256(t->seg_row.size() * 4) + align256(t->seg_len.size() * 4) +
+           align256(t->labhash.size() * sizeof(mc_slot)) + align256(t->lab_off.size() * 4) +
+           align256(t->lab_units.size() * 4) + align256(t->lab_cand_off.size() * 4) + align256(t->lab_cand.size() * 4) +
+           align256(t->np_len.size() * 4) + align256(t->np_off.size() * 4) + align256(t->np_cand.size() * 4);
 }

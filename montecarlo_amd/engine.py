@@ -117,6 +117,18 @@ class DeviceModel:
         return res, split
 
 
+    def score_bpe(self, cps: np.ndarray, cls: np.ndarray, off: np.ndarray) -> torch.Tensor:
+        count = len(off) - 1
+        with torch.cuda.device(self.tdev):
+            d_cps = torch.from_numpy(np.ascontiguousarray(cps, dtype=np.uint32).view(np.int32)).to(self.tdev)
+            d_cls = torch.from_numpy(np.ascontiguousarray(cls, dtype=np.uint8)).to(self.tdev)
+            d_off = torch.from_numpy(np.ascontiguousarray(off, dtype=np.uint64).view(np.int64)).to(self.tdev)
+            res = torch.empty(count, dtype=torch.float64, device=self.tdev)
+            nv.check(nv.lib.mc_score_bpe(self._h, _vp(d_cps), _vp(d_cls), _vp(d_off), count, _vp(res), self._stream()))
+            torch.cuda.current_stream(self.tdev).synchronize()      # inputs must outlive the kernel
+        return res
+
+
 class DeviceRank:
     """Sorted keys + positions on one GPU (MonteCarloLib.__init__, lib4mc/MonteCarloLib.py:10-28)."""
 

@@ -98,7 +98,7 @@ class MonteCarlo(metaclass=abc.ABCMeta):
             return self._sample_by_loop(size, sampled_pwds, clearIfNotNone)
         seed, first = self._claim_ids(size)
         want = isinstance(sampled_pwds, dict)
-        stride = 32 if want else 0
+        stride = self._sample_stride() if want else 0
         res = self._dev.sample(size, seed, first_id=first, max_draws=self.max_draws, sym_stride=stride)
         self._dev.check()
         if want:
@@ -115,6 +115,10 @@ class MonteCarlo(metaclass=abc.ABCMeta):
                 sampled_pwds.clear()
             sampled_pwds.update(seen)
         return SampleKeys(res["ml2p"])
+
+    def _sample_stride(self) -> int:
+        """Symbols kept per sample when strings are wanted (longer ones are replayed one by one)."""
+        return 32
 
     def _strings_of(self, res, seed: int, first: int) -> List[str]:
         lens = res["len"].cpu().numpy()

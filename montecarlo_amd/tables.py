@@ -188,3 +188,120 @@ class FlatTable:
                 parts = [c for c in parts if c != drop]
             out.append("".join(parts))
         return out
+
+
+class BpeFlat(FlatTable):
+    """Two-level BPE-PCFG table (bpe_simulator.py:152-156): row 0 = the grammar (entry i = structure
+    i, in ``expand_1d`` order), rows 1.. = the terminal rows of ``expand_2d`` in dict order.  A
+    structure's segments name terminal rows; the label / not_parsed index of ``count_luds`` is
+    flattened beside it for the scoring kernel."""
+
+    def __init__(self, grammars, terminals, converted, not_parsed, class_of, guide_factor: Optional[int] = None):
+        if guide_factor is None:
+            guide_factor = int(os.environ.get("MC_GUIDE_FACTOR", "4"))
+        g_vals, g_keys, g_cum = grammars
+        self.kind = nv.KIND_BPE
+        self.structures = list(g_keys)
+        struct_id = {st: i for i, st in enumerate(self.structures)}
+        row_of = {key: r + 1 for r, key in enumerate(terminals)}
+        n_struct, n_ctx = len(self.structures), 1 + len(terminals)
+        # symbols: one (textless) id per structure, one per distinct terminal string, a textless end marker
+        symbols: List[str] = [""] * n_struct
+        sym_id: Dict[str, int] = {}
+        ent_sym: List[int] = list(range(n_struct))
+        ent_ml2p: List[float] = [g_vals[k] for k in g_keys]
+        cums = [np.asarray(g_cum, dtype=np.float64)]
+        row_off = np.zeros(n_ctx + 1, dtype=np.uint64)
+        row_off[1] = n_struct
+        self.entry_text: List[str] = [""] * n_struct
+        for r, (key, (vals, keys, cum)) in enumerate(terminals.items()):
+            for k in keys:
+                i = sym_id.get(k)
+                if i is None:
+                    i = sym_id[k] = len(symbols)
+                    symbols.append(k)
+                ent_sym.append(i)
+                ent_ml2p.append(vals[k])
+            self.entry_text.extend(keys)
+            cums.append(np.asarray(cum, dtype=np.float64))
+            row_off[r + 2] = len(ent_sym)
+        end_sym = len(symbols)
+        symbols.append("")
+        self.symbols, self.sym_id, self.end_sym, self.end_chr = symbols, sym_id, end_sym, ""
+        seg_off = np.zeros(n_struct + 1, dtype=np.uint32)
+        seg_row: List[int] = []
+        seg_len: List[int] = []
+        for i, st in enumerate(self.structures):
+            for tag, ln in st:
+                seg_row.append(row_of.get((tag, ln), nv.MC_NONE))
+                seg_len.append(ln)
+            seg_off[i + 1] = len(seg_row)
+        self.max_segments = max(1, int(np.diff(seg_off).max()) if n_struct else 1)
+        labels = [lab for lab in converted if all(tag in class_of for tag, _ in lab)]   # luds only emits L/U/D/S
+        lab_off = np.zeros(len(labels) + 1, dtype=np.uint32)
+        lab_cand_off = np.zeros(len(labels) + 1, dtype=np.uint32)
+        lab_units: List[int] = []
+        lab_cand: List[int] = []
+        for j, lab in enumerate(labels):
+            lab_units.extend((class_of[tag] << 24) | ln for tag, ln in lab)
+            lab_off[j + 1] = len(lab_units)
+            lab_cand.extend(sorted(struct_id[st] for st in converted[lab]))
+            lab_cand_off[j + 1] = len(lab_cand)
+        np_len = np.array(list(not_parsed), dtype=np.uint32)
+        np_off = np.zeros(len(not_parsed) + 1, dtype=np.uint32)
+        np_cand: List[int] = []
+        for k, total in enumerate(not_parsed):
+            np_cand.extend(sorted(struct_id[st] for st in not_parsed[total]))
+            np_off[k + 1] = len(np_cand)
+
+        ctx_off = np.arange(n_ctx + 1, dtype=np.uint32)
+        ctx_units = np.arange(n_ctx, dtype=np.uint32)
+        a_ent_sym = np.array(ent_sym, dtype=np.uint32)
+        a_cum = np.concatenate(cums)
+        a_ml2p = np.array(ent_ml2p, dtype=np.float64)
+        a_chars = np.array([len(s) for s in symbols], dtype=np.uint32)
+        text_off = np.zeros(len(symbols) + 1, dtype=np.uint32)
+        np.cumsum(a_chars, out=text_off[1:])
+        a_text = np.frombuffer("".join(symbols).encode("utf-32-le", "surrogatepass"), dtype="<u4").astype(np.uint32)
+        start_ids = np.zeros(1, dtype=np.uint32)
+        a_seg_row, a_seg_len = np.array(seg_row, dtype=np.uint32), np.array(seg_len, dtype=np.uint32)
+        a_lab_units, a_lab_cand = np.array(lab_units, dtype=np.uint32), np.array(lab_cand, dtype=np.uint32)
+        a_np_cand = np.array(np_cand, dtype=np.uint32)
+        keep = [ctx_off, ctx_units, row_off, a_ent_sym, a_cum, a_ml2p, a_chars, text_off, a_text, start_ids, seg_off,
+                a_seg_row, a_seg_len, lab_off, lab_cand_off, a_lab_units, a_lab_cand, np_len, np_off, a_np_cand]
+
+        d = nv.ModelDesc()
+        d.kind, d.order, d.n_ctx, d.n_sym, d.n_ent = nv.KIND_BPE, 0, n_ctx, len(symbols), len(ent_sym)
+        d.ctx_off, d.ctx_units = _ptr(ctx_off, nv.u32p), _ptr(ctx_units, nv.u32p)
+        d.row_off, d.ent_sym = _ptr(row_off, nv.u64p), _ptr(a_ent_sym, nv.u32p)
+        d.ent_cum, d.ent_ml2p = _ptr(a_cum, nv.f64p), _ptr(a_ml2p, nv.f64p)
+        d.sym_chars = _ptr(a_chars, nv.u32p)
+        d.start_units, d.n_start = _ptr(start_ids, nv.u32p), 1
+        d.end_sym, d.min_len, d.max_len, d.flags, d.guide_factor = end_sym, 0, 1 << 30, 0, guide_factor
+        d.sym_text_off, d.sym_text = _ptr(text_off, nv.u32p), _ptr(a_text, nv.u32p)
+        d.seg_off, d.seg_row, d.seg_len = _ptr(seg_off, nv.u32p), _ptr(a_seg_row, nv.u32p), _ptr(a_seg_len, nv.u32p)
+        d.n_labels, d.n_np = len(labels), len(np_len)
+        d.lab_off, d.lab_units = _ptr(lab_off, nv.u32p), _ptr(a_lab_units, nv.u32p)
+        d.lab_cand_off, d.lab_cand = _ptr(lab_cand_off, nv.u32p), _ptr(a_lab_cand, nv.u32p)
+        d.np_len, d.np_off, d.np_cand = _ptr(np_len, nv.u32p), _ptr(np_off, nv.u32p), _ptr(a_np_cand, nv.u32p)
+        handle = C.c_void_p()
+        nv.check(nv.lib.mc_table_compile(C.byref(d), C.byref(handle)))
+        del keep
+        self._h = handle
+        info = (C.c_uint64 * 16)()
+        nv.check(nv.lib.mc_table_info(self._h, info))
+        self.info = list(info)
+        self.multichar = True
+        self.max_word_len = int(self.info[nv.INFO_MULTICHAR] >> 8)
+        self._lut = None
+        self.ctx_row = dict(row_of)
+        # what was handed to the compiler, for tests/walker.py
+        self.seg = (seg_off.copy(), a_seg_row.copy(), a_seg_len.copy())
+        self.label_index = {tuple((class_of[tag] << 24) | ln for tag, ln in lab):
+                            lab_cand[lab_cand_off[j]:lab_cand_off[j + 1]] for j, lab in enumerate(labels)}
+        self.np_index = {int(total): np_cand[np_off[k]:np_off[k + 1]] for k, total in enumerate(not_parsed)}
+
+    def decode_entries(self, ents: np.ndarray, lens: np.ndarray) -> List[str]:
+        """Rows of terminal ENTRY indices (k_sample_bpe's out_syms) -> sampled strings."""
+        text = self.entry_text
+        return ["".join(text[e] for e in row[:n]) for row, n in zip(ents, lens)]

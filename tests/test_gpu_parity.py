@@ -114,6 +114,42 @@ def test_subword_scoring(train_tab, train_char):
     assert np.isnan(res.cpu().numpy()[1])
 
 
+def test_bpe_pcfg():
+    """BpePcfgSim on the GPU: samples (Philox and injected uniforms) and calc_ml2p against the
+    reference's recorded values; the plugin surface end to end (sample -> MonteCarloLib ->
+    parse_file -> ml2p_iter2gc), which the reference itself cannot run."""
+    import os
+    from conftest import GOLDEN
+    from montecarlo_amd.bpe_simulator import BpePcfgSim
+    fx = golden("bpe.json")
+    m = BpePcfgSim(os.path.join(GOLDEN, "bpe_model"))
+    items, seed = fx["samples"]["items"], fx["samples"]["seed"]
+    for injected in (False, True):
+        if injected:
+            dmax = max(it[2] for it in items)
+            u = np.array([[uniform53(seed, i, k) for k in range(dmax)] for i in range(len(items))])
+            res = m._dev.sample_injected(u, sym_stride=m._flat.max_segments)
+        else:
+            res = m._dev.sample(len(items), seed, want_draws=True, want_len=True, sym_stride=m._flat.max_segments)
+        m._dev.check()
+        strings = m._flat.decode_entries(res["syms"].cpu().numpy(), res["len"].cpu().numpy())
+        got = [[hx(a), s, int(d)] for a, s, d in zip(res["ml2p"].cpu().numpy(), strings, res["draws"].cpu().numpy())]
+        assert got == items
+    pw = [s[0] for s in fx["scores"]] + ["", "zzzzzzzzzzzzzzzzzzzzzzzzzzzzzz"]
+    ml2p, parts = m.score_batch(pw)
+    assert [hx(x) for x in ml2p[:-2]] == [s[1] for s in fx["scores"]]
+    assert ml2p[-2:] == [1022.0, 1022.0] and parts[0] == [pw[0]]
+    assert m.calc_ml2p(pw[0]) == (fh(fx["scores"][0][1]), [pw[0]])
+    m.seed(seed)
+    seen = {}
+    keys = m.sample(len(items), seen)
+    assert [hx(x) for x in keys] == [it[0] for it in items]
+    assert list(seen)[:3] == list(dict.fromkeys(it[1] for it in items))[:3]
+    mc = MonteCarloLib(keys)
+    gc = mc.ml2p_iter2gc(m.parse_file(synth.as_file([s[0] for s in fx["scores"]])), need_resort=True)
+    assert len(gc) == len(fx["scores"]) and all(a[3] < b[3] for a, b in zip(gc, gc[1:]))
+
+
 def test_secondary_and_v2(train_char, train_v2):
     fx = golden("secondary_thr4_char.json")
     cfg = {"start_chr": "\x03", "end_chr": "\x00", "threshold": 4}

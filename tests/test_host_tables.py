@@ -142,6 +142,22 @@ def test_v2(train_v2):
     check_walk(fx, m, keep_len=True)
 
 
+def test_bpe():
+    """BPE-PCFG (bpe_simulator.py:104-157): the two-level compiled table walked as k_sample_bpe /
+    k_score_bpe walk it, against the reference's samples and calc_ml2p values (golden/bpe.json)."""
+    from montecarlo_amd.bpe_simulator import BpePcfgSim, char_class, luds
+    fx = golden("bpe.json")
+    m = BpePcfgSim(os.path.join(GOLDEN, "bpe_model"))
+    w = CompiledWalker(m._flat)
+    seed = fx["samples"]["seed"]
+    for i, (want, pwd, draws) in enumerate(fx["samples"]["items"][:300]):
+        acc, ents, used = w.sample_bpe(SampleStream(seed, i))
+        assert (hx(acc), "".join(m._flat.entry_text[e] for e in ents), used) == (want, pwd, draws), i
+    for pwd, want in fx["scores"]:
+        assert hx(w.score_bpe(pwd, [char_class(c) for c in pwd])) == want, pwd
+    assert luds("") == ((" ", 0),) and luds("ab1!") == (("L", 2), ("D", 1), ("S", 1))
+
+
 def test_draw_table_equals_bisect(train_char):
     """The bucketed draw table returns bisect_right(cum, total*r) (clamped to the last entry, the
     reference raises there) for r at every bucket's edges, just inside them, at every threshold

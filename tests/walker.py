@@ -181,3 +181,49 @@ class CompiledWalker:
             if not advanced:
                 stack.pop()
         return best, best_ends
+
+    # mirrors k_sample_bpe: (ml2p, terminal entry indices, draws)
+    def sample_bpe(self, uniform):
+        seg_off, seg_row, _ = self.flat.seg
+        q, _ = self.lookup(self.start_draw, self.start_gbits, uniform())
+        acc, st, draws, ents = self.f64(q), int(q[2]), 1, []
+        for k in range(int(seg_off[st]), int(seg_off[st + 1])):
+            row = int(seg_row[k])
+            if row == NONE:
+                return float("nan"), ents, draws
+            rec = self.state[row]
+            q, _ = self.lookup(int(rec["guide_off"]), int(rec["gbits"]), uniform())
+            draws += 1
+            acc += self.f64(q)
+            ents.append(int(q[2]))
+        return acc, ents, draws
+
+    # mirrors k_score_bpe
+    def score_bpe(self, pwd, classes):
+        seg_off, seg_row, seg_len = self.flat.seg
+        units, j = [], 0
+        while j < len(pwd):
+            e = j + 1
+            while e < len(pwd) and classes[e] == classes[j]:
+                e += 1
+            units.append((classes[j] << 24) | (e - j))
+            j = e
+        cand = self.flat.label_index.get(tuple(units), []) if pwd else []
+        if not cand:
+            cand = self.flat.np_index.get(len(pwd), [])
+        best = 1022.0
+        for st in cand:
+            p, start, ok = float(self.payload[st]["ml2p"]), 0, True
+            for k in range(int(seg_off[st]), int(seg_off[st + 1])):
+                row, tl = int(seg_row[k]), int(seg_len[k])
+                piece = pwd[start:start + tl]
+                start += tl
+                sym = self.word([ord(c) for c in piece]) if (row != NONE and piece) else NONE
+                ent = self.find(row, sym) if sym != NONE else NONE
+                if ent == NONE:
+                    ok = False
+                    break
+                p += float(self.payload[ent]["ml2p"])
+            if ok and p < 1022.0 and p < best:
+                best = p
+        return best

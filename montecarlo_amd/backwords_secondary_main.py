@@ -1,0 +1,196 @@
+"""Secondary training loop (BASELINE config 5): the reference's ``backwords_secondary_main.py``
+(:19-251) with the same command line, round body and output files; every round's sampling,
+scoring, sort/scan and rank queries run on the GPU through the lib4mc classes of this package.
+
+One round (``secondary_cracker``, reference :19-88): merge the round's training passwords into the
+raw counts -> model -> sample `size` strings -> guess-number curve -> score the test set -> pick the
+cracked passwords (``samples`` strategy: the test passwords whose STRING was sampled, guess number =
+1 + samples sorted before it) -> they are the next round's training data.
+
+Reproducibility: every round's model draws its Philox seed from ``random.getrandbits(64)`` on first
+use, so ``random.seed(x)`` before ``wrapper()`` fixes the whole run (tests/golden/make_golden_secondary.py
+pins it against the reference run with the same streams injected)."""
+import argparse
+import json
+import math
+import os
+import pickle
+import random
+import sys
+from typing import List, Tuple
+
+from .backwords.backwords_secondary_trainer import backwords_counter
+from .backwords_secondary_simulator import BackWordsSecondaryMonteCarlo
+from .lib4mc.FileLib import wc_l
+from .lib4mc.MonteCarloLib import MonteCarloLib
+
+GN_CAP = 10 ** 14       # the reference's `upper_bound` / `hits_upper_bound` (:137)
+
+
+def secondary_cracker(backwords, words, config, func_threshold: Tuple[int, int], **kwargs):
+    save_dir, tag, splitter = kwargs['save'], kwargs['tag'], kwargs['splitter']
+    counts, words = backwords_counter(
+        nwords_list=kwargs['training'], splitter=splitter, start_chr=config['start_chr'], end_chr=config['end_chr'],
+        start4words=kwargs['start4words'], step4words=kwargs['skip4words'], max_gram=kwargs['max_gram'],
+        nwords_dict=backwords, words=words, threshold=kwargs['threshold'])
+    config['training_list'].append(f"{kwargs['sign']}")
+    with open(os.path.join(save_dir, f"model-to-crack-{tag}.pickle"), 'wb') as fd:
+        pickle.dump((counts, words, config), file=fd)
+    model = BackWordsSecondaryMonteCarlo((counts, words, config), max_iter=kwargs['max_iter'])
+
+    by_samples = kwargs['using_sample_attack']
+    sampled = {} if by_samples else None
+    keys = model.sample(size=kwargs['size'], sampled_pwds=sampled)
+    if by_samples:
+        # samples in ascending -log2 p (ties: first sampled first); a string's guess number is
+        # 1 + the number of samples, with multiplicity, written before it (:45-51)
+        with open(os.path.join(save_dir, f"samples-{tag}.txt"), 'w') as fout:
+            before = 1
+            for pwd, (prob, cnt) in sorted(sampled.items(), key=lambda kv: kv[1][0]):
+                fout.write(f"{pwd}\t{prob:.8f}\t{cnt}\n")
+                sampled[pwd] = before
+                before += cnt
+    mc = MonteCarloLib(keys)
+    gc = mc.ml2p_iter2gc(minus_log_prob_iter=model.parse_file(kwargs['testing'], using_component=True))
+
+    next_training: List[str] = []
+    done, cum = kwargs['already_cracked'], kwargs['cum']
+    gn_bound, hits_bound = func_threshold
+    hits, max_gn = 0, 0
+    with open(os.path.join(save_dir, f"cracked-{tag}.txt"), 'w') as fout:
+        for parts, prob, num, gn, _cracked, _ratio in gc:
+            pwd = splitter.join(parts)
+            if pwd in done:
+                continue
+            hit = by_samples and pwd in sampled
+            if hit:
+                gn = sampled[pwd]
+            if hit or (not by_samples and gn < gn_bound and hits < hits_bound):
+                hits += 1
+                max_gn = max(max_gn, gn)
+                next_training.extend([pwd] * num)
+                cum.append((pwd, prob, num, gn))
+                fout.write(f"{pwd}\t{prob:.8f}\t{num}\t{gn}\n")
+                done.add(pwd)
+    keep = kwargs['secondary_sample']
+    if keep < len(next_training):
+        print(f"We sample {keep} passwords to perform secondary training in the next round", file=sys.stderr)
+        next_training = random.sample(next_training, keep)
+        with open(os.path.join(save_dir, f"sampled-{tag}.txt"), 'w') as fout:
+            fout.writelines(f"{pwd}\n" for pwd in next_training)
+    return counts, words, config, next_training, max_gn
+
+
+def build_cli() -> argparse.ArgumentParser:
+    cli = argparse.ArgumentParser('Backwords secondary main')
+    cli.add_argument("-i", "--training", dest="training", type=argparse.FileType('r'), required=True,
+                     help="The training file, each password a line")
+    cli.add_argument("-t", "--testing", dest="testing", type=argparse.FileType('r'), required=True,
+                     help="The testing file, each password a line")
+    cli.add_argument("-s", "--save", dest="save", required=True, type=str,
+                     help="A folder, results will be saved in this folder")
+    cli.add_argument("--strategy", dest="strategy", required=True, type=str, nargs="+",
+                     help="`guesses <g1> <g2> ...` guess number thresholds per round; `hits <h1> <h2> ...` cracked "
+                          "passwords per round; `auto_hits <factor> <base> <termination>`; `samples <rounds>` "
+                          "rounds of Monte Carlo simulation whose sampled strings are the guesses")
+    cli.add_argument("--size", dest="size", type=int, required=False, default=100000, help="sample size")
+    cli.add_argument("--secondary-sample", dest="secondary_sample", type=int, required=False, default=10000000000,
+                     help="use some of the cracked passwords for secondary training.")
+    cli.add_argument("--splitter", dest="splitter", type=str, required=False, default="empty",
+                     help="column separator of the input file: \"empty\" for '', \"space\" for ' ', \"tab\" for '\\t'")
+    cli.add_argument("--start4word", dest="start4words", type=int, required=False, default=0,
+                     help="index of the first word among the columns of a line")
+    cli.add_argument("--skip4word", dest="skip4words", type=int, required=False, default=1,
+                     help="step between words among the columns (to skip tags between them)")
+    cli.add_argument("--max-gram", dest="max_gram", required=False, type=int, default=256, help="max gram")
+    cli.add_argument("--threshold", dest="threshold", required=False, type=int, default=10,
+                     help="grams whose frequencies less than the threshold will be ignored")
+    cli.add_argument("--max-iter", dest="max_iter", required=False, default=10 ** 20, type=int,
+                     help="max iteration when calculating the maximum probability of a password")
+    return cli
+
+
+def plan_rounds(strategy: List[str], size: int):
+    """(per-round (guess bound, hit bound), per-round sign, sample attack?) -- reference :136-170."""
+    kind, values = strategy[0], strategy[1:]
+    if kind == 'guesses':
+        return [(int(v), GN_CAP) for v in values], [f"guesses-{int(v):,}" for v in values], False
+    if kind == 'hits':
+        return [(GN_CAP, int(v)) for v in values], [f"hits-{int(v):,}" for v in values], False
+    if kind == 'auto_hits':
+        factor, base, termination = int(values[0]), int(values[1]), int(values[2])
+        end = math.ceil(math.log(termination / max(base, 1)) / math.log(max(factor, 1)))
+        steps = list(range(1, end))
+        return [(GN_CAP, factor ** v * base) for v in steps], [f"auto_hits-{v:,}" for v in steps], False
+    rounds = int(values[0])
+    return [(GN_CAP, GN_CAP)] * rounds, [f"samples-{size}"] * rounds, True
+
+
+def wrapper(argv=None):
+    args = build_cli().parse_args(argv)
+    permits = {'guesses', 'hits', 'samples', 'auto_hits'}
+    if args.strategy[0] not in permits:
+        print(f"strategy should be one of `{', '.join(permits)}`", file=sys.stderr)
+        return
+    if len(args.strategy) < 2:
+        print("strategy should have at least 2 values", file=sys.stderr)
+        return
+    print(f"using {args.strategy[0]}", file=sys.stderr)
+    bounds, signs, by_samples = plan_rounds(args.strategy, args.size)
+    args.splitter = {'empty': '', 'space': ' ', 'tab': '\t'}.get(args.splitter.lower(), args.splitter)
+    start_chr, end_chr = '\x03', '\x00'                                 # reversed w.r.t. the plain simulators (:175)
+    config = {'start_chr': start_chr, 'end_chr': end_chr, 'max_gram': args.max_gram, 'threshold': args.threshold,
+              'training_list': [args.training.name]}
+    if not os.path.exists(args.save):
+        os.mkdir(args.save)
+    counts, words, training = None, None, args.training
+    already_cracked = set()
+    print(f"We will have {len(bounds)} rounds", file=sys.stderr, end=', ')
+    cums: List[List[Tuple[str, float, int, int]]] = []
+    max_gns: List[int] = []
+    for idx, bound in enumerate(bounds):
+        print(f"The {idx}-th iteration", file=sys.stderr)
+        cum: List[Tuple[str, float, int, int]] = []
+        counts, words, config, training, max_gn = secondary_cracker(
+            counts, words, config=config, func_threshold=bound, training=training, splitter=args.splitter,
+            start4words=args.start4words, skip4words=args.skip4words, max_gram=args.max_gram, size=args.size,
+            max_iter=args.max_iter, testing=args.testing, save=args.save, secondary_sample=args.secondary_sample,
+            already_cracked=already_cracked, cum=cum, threshold=args.threshold, sign=signs[idx],
+            using_sample_attack=by_samples, tag=f"iter-{idx}")
+        cums.append(cum)
+        max_gns.append(max_gn)
+        if max_gn >= GN_CAP:
+            print(f"Too large guess number reached: {max_gn}, the training process is terminated", file=sys.stderr)
+            break
+    # the last round's cracked passwords go into the final model
+    counts, words = backwords_counter(
+        training, splitter=args.splitter, start_chr=start_chr, end_chr=end_chr, start4words=args.start4words,
+        step4words=args.skip4words, max_gram=args.max_gram, nwords_dict=counts, words=words, threshold=args.threshold)
+    with open(os.path.join(args.save, "final_model.pickle"), 'wb') as fout:
+        pickle.dump((counts, words, config), file=fout)
+    print("Training phase done.", file=sys.stderr)
+    model = BackWordsSecondaryMonteCarlo((counts, words, config), max_iter=args.max_iter)
+    mc = MonteCarloLib(model.sample(size=args.size))
+    gc = mc.ml2p_iter2gc(minus_log_prob_iter=model.parse_file(args.testing))
+    # what the final model alone cracks
+    with open(os.path.join(args.save, "iter_result.txt"), 'w') as fout:
+        cum = []
+        for pwd, prob, num, gn, cracked, ratio in gc:
+            fout.write(f"{pwd}\t{prob:.8f}\t{num}\t{gn}\t{cracked}\t{ratio:5.2f}\n")
+            if pwd not in already_cracked:
+                cum.append((pwd, prob, num, gn))
+        cums.append(cum)
+    # the union of all rounds: a round's guesses come after every guess of the rounds before it
+    with open(os.path.join(args.save, "sectional_result.txt"), "w") as fout:
+        cracked, total = 0, wc_l(args.testing)
+        for offset, cum in zip([0, *max_gns], cums):
+            for pwd, prob, num, gn in cum:
+                cracked += num
+                fout.write(f"{pwd}\t{prob:.8f}\t{num}\t{gn + offset}\t{cracked}\t{cracked / total * 100:5.2f}\n")
+    with open(os.path.join(args.save, "config.json"), 'w') as fout:
+        json.dump(config, fp=fout, indent=2)
+    args.testing.close()
+
+
+if __name__ == '__main__':
+    wrapper()

@@ -4,7 +4,8 @@
 guess-number hot path on one GPU:
 
     sample N=1e7 strings (k_sample) -> radix sort + prefix sum of 1/(n p) (mc_rank_build)
-    -> score T=1e6 test passwords (k_score) -> bisect them into the curve (k_query)
+    || score T=1e6 test passwords (k_score, second stream: independent of the samples)
+    -> bisect them into the curve (k_query)
     [-> all-reduce of the per-test partial sums when world_size > 1]
 
 Inputs (compiled tables, encoded test set) are resident in HBM before the timed region.
@@ -61,6 +62,7 @@ def main():
     ap.add_argument("--tests", type=int, default=1_000_000)
     ap.add_argument("--train-lines", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial", action="store_true", help="score on the main stream instead of overlapping it")
     ap.add_argument("--cpu-samples", type=int, default=300_000)
     args = ap.parse_args()
 
@@ -94,25 +96,42 @@ def main():
     seed = 20250304
 
     ev = {k: [] for k in ("sample", "rank", "score", "query")}
+    side = None if args.serial else torch.cuda.Stream(device=dev)
+    main_stream = torch.cuda.current_stream(dev)
 
     def step(it: int, timed: bool):
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        """sample -> rank build on the main stream; the test set is scored on a second stream while
+        the rank build runs (it does not depend on the samples); the queries join the two."""
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
         first = (it * world + rank) * N                     # disjoint Philox sample ids per rank and step
         marks[0].record()
         dm.sample(N, seed, first_id=first, out=keys)
         marks[1].record()
+        if side is not None:
+            # beside the rank build (streaming kernels that leave the gather path idle), not beside
+            # k_sample (both are gather-bound: measured, they only slow each other down)
+            side.wait_event(marks[1])
+            with torch.cuda.stream(side):
+                marks[3].record()
+                dm.score_device(d_syms, d_off, T, out=t_ml2p)
+                marks[4].record()
         rk = DeviceRank(keys, n_global=N * world, workspace=ws, keys_sorted=keys_sorted, positions=positions)
         marks[2].record()
-        dm.score_device(d_syms, d_off, T, out=t_ml2p)
-        marks[3].record()
+        if side is None:
+            marks[3].record()
+            dm.score_device(d_syms, d_off, T, out=t_ml2p)
+            marks[4].record()
+        else:
+            main_stream.wait_event(marks[4])
+        marks[5].record()
         rk.query(t_ml2p, out_pos=q_pos, out_cnt=q_cnt)
         mcd.combine_partials(q_pos, q_cnt)                  # one RCCL all-reduce each; no-op on one GPU
-        marks[4].record()
+        marks[6].record()
         if timed:
             ev["sample"].append((marks[0], marks[1]))
             ev["rank"].append((marks[1], marks[2]))
-            ev["score"].append((marks[2], marks[3]))
-            ev["query"].append((marks[3], marks[4]))
+            ev["score"].append((marks[3], marks[4]))
+            ev["query"].append((marks[5], marks[6]))
 
     def fence():
         torch.cuda.synchronize()
@@ -163,7 +182,7 @@ def main():
                                    "training lines), 1e7 samples + 1e6 test pwds per GPU per step",
                        "samples_per_gpu": N, "test_pwds": T, "contexts": int(flat.info[nv.INFO_NCTX]),
                        "entries": int(flat.info[nv.INFO_NENT]), "table_bytes": int(flat.info[nv.INFO_DEVICE_BYTES])},
-            "stage_ms": ms,
+            "stage_ms": ms, "score_overlapped": side is not None,
             "sampling_only_per_s": N * world / (ms["sample"] * 1e-3),
             "guess_numbers_per_s": T / ((ms["score"] + ms["query"]) * 1e-3),
             "draws_per_sample": draws / N, "indirect_draws_per_draw": indirect / max(draws, 1),

@@ -46,7 +46,8 @@ enum {
 };
 
 enum {
-    MC_FLAG_KEEP_LEN_ON_RESTART = 1u /* nwords_simulator_v2.py:73-81: pwd_len is not reset on restart */
+    MC_FLAG_KEEP_LEN_ON_RESTART = 1u, /* nwords_simulator_v2.py:73-81: pwd_len is not reset on restart */
+    MC_FLAG_NO_DENSE = 2u             /* do not build the dense (row, symbol) scoring table (MC_ARR_DENSE) */
 };
 
 #define MC_NONE 0xFFFFFFFFu  /* "no row" / unknown symbol id */
@@ -131,7 +132,11 @@ enum {
     MC_ARR_RCUM = 8,     /* double[n_ent]: per-entry thresholds in the uniform's domain (see mc_draw_rec) */
     MC_ARR_WORDHASH = 9, /* mc_slot[word_cap]: key = mc_text_hash(symbol text), val = symbol id, pad = length */
     MC_ARR_SYMTEXTOFF = 10, /* uint32[n_sym+1] */
-    MC_ARR_SYMTEXT = 11  /* uint32[]: code points */
+    MC_ARR_SYMTEXT = 11, /* uint32[]: code points */
+    MC_ARR_DENSE = 12    /* mc_payload[n_ctx * n_sym] or empty: for single-character alphabets small enough
+                          * (n_ctx * n_sym <= 2^22), the transition (row, symbol) with the backoff already
+                          * resolved: {ml2p, next, entry} of the longest suffix row that lists the symbol
+                          * (backwords_simulator.py:31-38), entry = MC_NONE when there is none */
 };
 int64_t mc_table_array(const mc_table *t, int what, void *dst, size_t cap);
 /* start state, end symbol, root (zero-gram) row, table sizes ... as 16 uint64 (see mc_table_info_idx) */

@@ -59,6 +59,7 @@ struct DevModel {
     const uint32_t *sym_chars;
     const Slot *wordhash;
     const uint32_t *sym_text_off, *sym_text;
+    const Payload *dense;
     unsigned long long *status;
     unsigned long long trans_mask, ctx_mask;
     uint32_t start_state, root, end_sym, min_len, max_len, flags, n_ctx, n_sym;
@@ -79,6 +80,7 @@ struct SampleArgs {
     double *out_ml2p;
     uint32_t *out_len, *out_draws, *out_syms;
     uint32_t max_draws, sym_stride;
+    uint32_t hot_recs;  // draw-table records cached in LDS by k_sample
 };
 
 constexpr uint32_t PH_M0 = 0xD2511F53u, PH_M1 = 0xCD9E8D57u, PH_W0 = 0x9E3779B9u, PH_W1 = 0xBB67AE85u;
@@ -123,8 +125,13 @@ __device__ __forceinline__ double rec_f64(const DrawRec &q) {
 // strings are written at the end of the iteration, so no load waits behind a store.
 template <bool INJECT, bool MULTICHAR, int NC>
 __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
+    // the head of the draw table (the rows with the most visits per bucket: mc_table.cpp places them
+    // first) lives in LDS: a.hot_recs records, loaded once per workgroup
+    extern __shared__ __align__(16) unsigned char hot_raw[];
+    DrawRec *hot = (DrawRec *)hot_raw;
     __shared__ unsigned int cursor;
     __shared__ unsigned int blk_cnt[5];
+    for (uint32_t i = threadIdx.x; i < a.hot_recs; i += blockDim.x) hot[i] = ((const DrawRec *)m.draw)[i];
     const unsigned long long per = (a.count + gridDim.x - 1) / gridDim.x;
     const unsigned long long b0 = min(a.count, (unsigned long long)blockIdx.x * per);
     const unsigned long long b1 = min(a.count, b0 + per);
@@ -204,7 +211,8 @@ __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
                     } else {
                         k = (uint32_t)(m53[c][h] >> (53u - gbits[c]));
                     }
-                    q[c] = dtab[goff[c] + k];
+                    const uint32_t at = goff[c] + k;
+                    if (at < a.hot_recs) q[c] = hot[at]; else q[c] = dtab[at];
                 }
             }
             // ---- phase 2: buckets that straddle thresholds: same index as
@@ -312,6 +320,26 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
     return z ^ (z >> 31);
 }
 
+__device__ __forceinline__ uint32_t find_entry(const DevModel &m, uint32_t state, uint32_t s, unsigned int &c_probe) {
+    uint32_t row = state;
+    while (row != MC_NONE) {  // longest suffix row that lists s (backwords_simulator.py:31-38)
+        const unsigned long long key = ((unsigned long long)row << 32) | s;
+        unsigned long long q = mix64(key + 0x9E3779B97F4A7C15ull) & m.trans_mask;
+        for (;;) {
+            const Slot sl = m.trans[q];
+            ++c_probe;
+            if (sl.key == key) return sl.val;
+            if (sl.key == ~0ull) break;
+            q = (q + 1) & m.trans_mask;
+        }
+        row = m.state[row].parent;
+    }
+    return MC_NONE;
+}
+
+// DENSE: the model has the resolved (row, symbol) table, a step is one 16-byte gather; otherwise
+// the (row,symbol) hash is probed along the backoff chain.
+template <bool DENSE>
 __global__ void __launch_bounds__(256) k_score(DevModel m, const uint32_t *__restrict__ syms,
                                                const unsigned long long *__restrict__ off, unsigned long long count,
                                                double *__restrict__ out) {
@@ -322,34 +350,31 @@ __global__ void __launch_bounds__(256) k_score(DevModel m, const uint32_t *__res
         uint32_t state = m.start_state;
         double acc = 0.0;
         bool ok = true;
+        uint32_t s_next = a < b ? syms[a] : m.end_sym;
         for (unsigned long long j = a; j <= b; ++j) {
-            const uint32_t s = j < b ? syms[j] : m.end_sym;
+            const uint32_t s = s_next;
+            // the next symbol is requested before this step's gather, so the two are in flight together
+            s_next = j + 1 < b ? syms[j + 1] : m.end_sym;
             if (s >= m.n_sym || state == MC_NONE) {
                 ok = false;
                 break;
             }
-            uint32_t row = state, e = MC_NONE;
-            while (row != MC_NONE) {  // longest suffix row that lists s (backwords_simulator.py:31-38)
-                const unsigned long long key = ((unsigned long long)row << 32) | s;
-                unsigned long long q = mix64(key + 0x9E3779B97F4A7C15ull) & m.trans_mask;
-                for (;;) {
-                    const Slot sl = m.trans[q];
-                    ++c_probe;
-                    if (sl.key == key) {
-                        e = sl.val;
-                        break;
-                    }
-                    if (sl.key == ~0ull) break;
-                    q = (q + 1) & m.trans_mask;
+            Payload p;
+            if (DENSE) {
+                p = m.dense[(size_t)state * m.n_sym + s];
+                ++c_probe;
+                if (p.sym == MC_NONE) {
+                    ok = false;
+                    break;
                 }
-                if (e != MC_NONE) break;
-                row = m.state[row].parent;
+            } else {
+                const uint32_t e = find_entry(m, state, s, c_probe);
+                if (e == MC_NONE) {
+                    ok = false;
+                    break;
+                }
+                p = m.payload[e];
             }
-            if (e == MC_NONE) {
-                ok = false;
-                break;
-            }
-            const Payload p = m.payload[e];
             acc += p.ml2p;
             state = p.next;
             ++c_step;
@@ -387,23 +412,6 @@ struct WordsArgs {
     Frame *stack;
     uint32_t split_words, max_len, n_lanes;
 };
-
-__device__ __forceinline__ uint32_t find_entry(const DevModel &m, uint32_t state, uint32_t s, unsigned int &c_probe) {
-    uint32_t row = state;
-    while (row != MC_NONE) {  // longest suffix row that lists s (backwords_simulator.py:31-38)
-        const unsigned long long key = ((unsigned long long)row << 32) | s;
-        unsigned long long q = mix64(key + 0x9E3779B97F4A7C15ull) & m.trans_mask;
-        for (;;) {
-            const Slot sl = m.trans[q];
-            ++c_probe;
-            if (sl.key == key) return sl.val;
-            if (sl.key == ~0ull) break;
-            q = (q + 1) & m.trans_mask;
-        }
-        row = m.state[row].parent;
-    }
-    return MC_NONE;
-}
 
 __global__ void __launch_bounds__(256) k_score_words(DevModel m, WordsArgs a) {
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
@@ -734,6 +742,7 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 struct mc_model {
     int device;
     int n_cu;
+    unsigned long long n_draw;  // records in the draw table
     bool has_text;
     void *arena;
     size_t arena_bytes;
@@ -755,6 +764,7 @@ extern "C" int mc_model_upload(const mc_table *t, int device, mc_model **out) {
     m->device = device;
     m->multichar = t->multichar;
     m->has_text = !t->wordhash.empty();
+    m->n_draw = t->draw.size();
     m->arena_bytes = mc_table_device_bytes(t);
     hipError_t e = hipMalloc(&m->arena, m->arena_bytes);
     if (e != hipSuccess) {
@@ -788,6 +798,7 @@ extern "C" int mc_model_upload(const mc_table *t, int device, mc_model **out) {
     d.start_sym = t->start_sym;
     d.end_text_off = t->sym_text_off.empty() ? 0 : t->sym_text_off[t->end_sym];
     d.end_text_len = t->sym_text_off.empty() ? 0 : t->sym_text_off[t->end_sym + 1] - t->sym_text_off[t->end_sym];
+    d.dense = t->dense.empty() ? nullptr : (const Payload *)put(t->dense.data(), t->dense.size() * sizeof(mc_payload));
     d.seg_off = (const uint32_t *)put(t->seg_off.data(), t->seg_off.size() * 4);
     d.seg_row = (const uint32_t *)put(t->seg_row.data(), t->seg_row.size() * 4);
     d.seg_len = (const uint32_t *)put(t->seg_len.data(), t->seg_len.size() * 4);
@@ -854,12 +865,14 @@ extern "C" int mc_model_check(mc_model *m, void *stream, uint64_t counters[8]) {
     return MC_OK;
 }
 
-static int launch_sample(mc_model *m, bool inject, const SampleArgs &a, hipStream_t s) {
-    if (a.count == 0) return MC_OK;
+static int launch_sample(mc_model *m, bool inject, const SampleArgs &a_in, hipStream_t s) {
+    if (a_in.count == 0) return MC_OK;
     if (m->dev.start_state == MC_NONE) {
         mc_set_error("the start context has no row (the reference exits in pick_expand, ProbLib.py:32-36)");
         return MC_ERR_TABLE;
     }
+    SampleArgs a = a_in;
+    a.hot_recs = 0;
     if (m->dev.kind == MC_KIND_BPE) {
         unsigned long long want = (a.count + 255) / 256, cap = (unsigned long long)m->n_cu * 16;
         dim3 g((unsigned)(want < cap ? want : cap)), b(256);
@@ -868,29 +881,38 @@ static int launch_sample(mc_model *m, bool inject, const SampleArgs &a, hipStrea
         HIP_TRY(hipGetLastError());
         return MC_OK;
     }
-    // Workgroups of 256 lanes; 16 per CU, of which 7-8 are resident at a time: a workgroup owns a
+    // Workgroups of 256 lanes; 16 per CU, of which 8 are resident at a time: a workgroup owns a
     // contiguous range of sample ids, and the second half of the grid evens out the ranges whose
-    // strings came out long (measured: 16 per CU 12 % faster than 8, 64 slower again).  Two chains
-    // per lane.  Both are tuning knobs (results never depend on them: tests/test_gpu_parity.py).
-    // Each workgroup's share of the sample ids must fit u32.
-    static const int env_nc = getenv("MC_SAMPLE_CHAINS") ? atoi(getenv("MC_SAMPLE_CHAINS")) : 2;
+    // strings came out long (measured: 16 per CU 12 % faster than 8, 32 and 64 slower again).
+    // 19 KB of LDS per workgroup hold the head of the draw table (8 x 19 KB fit a CU; it serves 55 %
+    // of the draws of the headline model; 40 KB costs more in occupancy than it saves).  One or two
+    // chains per lane perform alike once the table is placed hot-first.  All are tuning knobs
+    // (results never depend on them: tests/test_gpu_parity.py).  Each workgroup's share of the
+    // sample ids must fit u32.
+    static const int env_nc = getenv("MC_SAMPLE_CHAINS") ? atoi(getenv("MC_SAMPLE_CHAINS")) : 1;
     static const int env_wg = getenv("MC_SAMPLE_WG_PER_CU") ? atoi(getenv("MC_SAMPLE_WG_PER_CU")) : 16;
+    static const int env_hot = getenv("MC_SAMPLE_HOT_KB") ? atoi(getenv("MC_SAMPLE_HOT_KB")) : 19;
     const int nc = inject ? 1 : env_nc;
+    {
+        unsigned long long recs = (unsigned long long)(env_hot < 0 ? 0 : env_hot > 150 ? 150 : env_hot) * 1024 / 16;
+        a.hot_recs = (uint32_t)(recs < m->n_draw ? recs : m->n_draw);
+    }
+    const size_t lds = (size_t)a.hot_recs * sizeof(DrawRec);
     unsigned long long want = (a.count + 64ull * nc - 1) / (64ull * nc);
     unsigned long long cap = (unsigned long long)m->n_cu * (env_wg > 0 ? env_wg : 16);
     unsigned long long grid = want < cap ? want : cap;
     while ((a.count + grid - 1) / grid > 0x7FFFFFFFull) grid *= 2;
     dim3 g((unsigned)grid), b(256);
     if (inject) {
-        if (m->multichar) hipLaunchKernelGGL((k_sample<true, true, 1>), g, b, 0, s, m->dev, a);
-        else hipLaunchKernelGGL((k_sample<true, false, 1>), g, b, 0, s, m->dev, a);
+        if (m->multichar) hipLaunchKernelGGL((k_sample<true, true, 1>), g, b, lds, s, m->dev, a);
+        else hipLaunchKernelGGL((k_sample<true, false, 1>), g, b, lds, s, m->dev, a);
     } else if (m->multichar) {
-        if (nc == 1) hipLaunchKernelGGL((k_sample<false, true, 1>), g, b, 0, s, m->dev, a);
-        else hipLaunchKernelGGL((k_sample<false, true, 2>), g, b, 0, s, m->dev, a);
+        if (nc == 2) hipLaunchKernelGGL((k_sample<false, true, 2>), g, b, lds, s, m->dev, a);
+        else hipLaunchKernelGGL((k_sample<false, true, 1>), g, b, lds, s, m->dev, a);
     } else {
-        if (nc == 1) hipLaunchKernelGGL((k_sample<false, false, 1>), g, b, 0, s, m->dev, a);
-        else if (nc == 4) hipLaunchKernelGGL((k_sample<false, false, 4>), g, b, 0, s, m->dev, a);
-        else hipLaunchKernelGGL((k_sample<false, false, 2>), g, b, 0, s, m->dev, a);
+        if (nc == 2) hipLaunchKernelGGL((k_sample<false, false, 2>), g, b, lds, s, m->dev, a);
+        else if (nc == 4) hipLaunchKernelGGL((k_sample<false, false, 4>), g, b, lds, s, m->dev, a);
+        else hipLaunchKernelGGL((k_sample<false, false, 1>), g, b, lds, s, m->dev, a);
     }
     HIP_TRY(hipGetLastError());
     return MC_OK;
@@ -903,7 +925,7 @@ extern "C" int mc_sample(mc_model *m, uint64_t first_id, uint64_t count, uint64_
         mc_set_error("mc_sample: bad argument");
         return MC_ERR_ARG;
     }
-    SampleArgs a{first_id, count, seed, nullptr, out_ml2p, out_len, out_draws, out_syms, max_draws, sym_stride};
+    SampleArgs a{first_id, count, seed, nullptr, out_ml2p, out_len, out_draws, out_syms, max_draws, sym_stride, 0};
     return launch_sample(m, false, a, (hipStream_t)stream);
 }
 
@@ -914,7 +936,7 @@ extern "C" int mc_sample_injected(mc_model *m, uint64_t count, const double *uni
         mc_set_error("mc_sample_injected: bad argument");
         return MC_ERR_ARG;
     }
-    SampleArgs a{0, count, 0, uniforms, out_ml2p, out_len, out_draws, out_syms, draws_per_sample, sym_stride};
+    SampleArgs a{0, count, 0, uniforms, out_ml2p, out_len, out_draws, out_syms, draws_per_sample, sym_stride, 0};
     return launch_sample(m, true, a, (hipStream_t)stream);
 }
 
@@ -932,8 +954,12 @@ extern "C" int mc_score(mc_model *m, const uint32_t *syms, const uint64_t *off, 
     }
     unsigned long long want = (count + 255) / 256, cap = (unsigned long long)m->n_cu * 8;
     dim3 g((unsigned)(want < cap ? want : cap)), b(256);
-    hipLaunchKernelGGL(k_score, g, b, 0, (hipStream_t)stream, m->dev, syms, (const unsigned long long *)off,
-                       (unsigned long long)count, out_ml2p);
+    if (m->dev.dense)
+        hipLaunchKernelGGL(k_score<true>, g, b, 0, (hipStream_t)stream, m->dev, syms, (const unsigned long long *)off,
+                           (unsigned long long)count, out_ml2p);
+    else
+        hipLaunchKernelGGL(k_score<false>, g, b, 0, (hipStream_t)stream, m->dev, syms,
+                           (const unsigned long long *)off, (unsigned long long)count, out_ml2p);
     HIP_TRY(hipGetLastError());
     return MC_OK;
 }

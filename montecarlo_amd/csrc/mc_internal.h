@@ -35,6 +35,7 @@ struct mc_table {
     std::vector<mc_slot> trans;
     std::vector<mc_slot> ctxhash;
     std::vector<uint32_t> sym_chars;
+    std::vector<mc_payload> dense;        // [n_ctx][n_sym] resolved transitions (small single-character alphabets)
     std::vector<mc_slot> wordhash;        // empty when the descriptor had no symbol text
     std::vector<uint32_t> sym_text_off, sym_text;
     uint32_t max_word_len, start_sym;

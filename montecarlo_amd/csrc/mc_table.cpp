@@ -316,7 +316,7 @@ extern "C" int mc_table_compile(const mc_model_desc *d, mc_table **out) {
             if (gbits > 16) gbits = 16;
         }
         st.gbits = gbits;
-        st.guide_off = (uint32_t)n_buckets;
+        st.guide_off = 0;  // assigned below, hottest rows first
         n_buckets += 1ull << gbits;
         if (n_buckets >= 0xFFFFFFF0ull) {
             mc_set_error("draw table exceeds 2^32 buckets; lower guide_factor");
@@ -335,6 +335,49 @@ extern "C" int mc_table_compile(const mc_model_desc *d, mc_table **out) {
             p.ml2p = d->ent_ml2p[e];
             p.next = bpe ? MC_NONE : state_of(seq.data(), (uint32_t)seq.size());
             p.sym = s | (s == d->end_sym ? 0x80000000u : 0u);
+        }
+    }
+    // ---- bucket placement: rows in descending order of expected visits per bucket, so that the
+    // head of the draw table is what the sampling kernel keeps in LDS.  Visits are propagated from
+    // the start row along the next-state links (restarts ignored): an estimate that only affects
+    // speed, never results.
+    {
+        std::vector<double> visits(d->n_ctx, 0.0), cur(d->n_ctx, 0.0), nxt(d->n_ctx, 0.0);
+        if (t->start_state != MC_NONE && !bpe) {
+            cur[t->start_state] = 1.0;
+            for (int step = 0; step < 48; ++step) {
+                std::fill(nxt.begin(), nxt.end(), 0.0);
+                double alive = 0.0;
+                for (uint32_t r = 0; r < d->n_ctx; ++r) {
+                    const double v = cur[r];
+                    if (v <= 0.0) continue;
+                    visits[r] += v;
+                    const mc_state_rec &st = t->state[r];
+                    double prev = 0.0;
+                    for (uint32_t j = 0; j < st.len; ++j) {
+                        const double c = t->cum[st.ent_off + j];
+                        const mc_payload &p = t->payload[st.ent_off + j];
+                        if (!(p.sym & 0x80000000u) && p.next != MC_NONE) {
+                            const double w = v * (c - prev) / st.total;
+                            nxt[p.next] += w;
+                            alive += w;
+                        }
+                        prev = c;
+                    }
+                }
+                cur.swap(nxt);
+                if (alive < 1e-9) break;
+            }
+        }
+        std::vector<uint32_t> order(d->n_ctx);
+        for (uint32_t r = 0; r < d->n_ctx; ++r) order[r] = r;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+            return visits[a] / (double)(1u << t->state[a].gbits) > visits[b] / (double)(1u << t->state[b].gbits);
+        });
+        uint64_t at = 0;
+        for (uint32_t r : order) {
+            t->state[r].guide_off = (uint32_t)at;
+            at += 1ull << t->state[r].gbits;
         }
     }
     if (t->start_state != MC_NONE) {
@@ -480,6 +523,26 @@ extern "C" int mc_table_compile(const mc_model_desc *d, mc_table **out) {
                 }
             }
         }
+    // ---- dense resolved transitions (scoring of small single-character alphabets) ------------
+    if ((d->kind == MC_KIND_NGRAM || d->kind == MC_KIND_BACKOFF) && !t->multichar && !(d->flags & MC_FLAG_NO_DENSE) &&
+        (uint64_t)d->n_ctx * d->n_sym <= (1ull << 22)) {
+        const uint32_t S = d->n_sym;
+        t->dense.assign((size_t)d->n_ctx * S, mc_payload{0.0, MC_NONE, MC_NONE});
+        // a row's own entries first, then whatever its parent resolves (parents have shorter contexts)
+        std::vector<uint32_t> order(d->n_ctx);
+        for (uint32_t r = 0; r < d->n_ctx; ++r) order[r] = r;
+        std::stable_sort(order.begin(), order.end(),
+                         [&](uint32_t a, uint32_t b) { return t->state[a].ctx_len < t->state[b].ctx_len; });
+        for (uint32_t r : order) {
+            mc_payload *row = t->dense.data() + (size_t)r * S;
+            const uint32_t par = t->state[r].parent;
+            if (par != MC_NONE) std::copy(t->dense.begin() + (size_t)par * S, t->dense.begin() + (size_t)(par + 1) * S, row);
+            for (uint64_t e = d->row_off[r]; e < d->row_off[r + 1]; ++e) {
+                const mc_payload &p = t->payload[e];
+                row[d->ent_sym[e]] = mc_payload{p.ml2p, p.next, (uint32_t)e};
+            }
+        }
+    }
     *out = t;
     return MC_OK;
 }
@@ -498,6 +561,7 @@ extern "C" int64_t mc_table_array(const mc_table *t, int what, void *dst, size_t
         case MC_ARR_WORDHASH: src = t->wordhash.data(); bytes = t->wordhash.size() * sizeof(mc_slot); break;
         case MC_ARR_SYMTEXTOFF: src = t->sym_text_off.data(); bytes = t->sym_text_off.size() * sizeof(uint32_t); break;
         case MC_ARR_SYMTEXT: src = t->sym_text.data(); bytes = t->sym_text.size() * sizeof(uint32_t); break;
+        case MC_ARR_DENSE: src = t->dense.data(); bytes = t->dense.size() * sizeof(mc_payload); break;
         case MC_ARR_CUM: src = t->cum.data(); bytes = t->cum.size() * sizeof(double); break;
         case MC_ARR_PAYLOAD: src = t->payload.data(); bytes = t->payload.size() * sizeof(mc_payload); break;
         case MC_ARR_TRANS: src = t->trans.data(); bytes = t->trans.size() * sizeof(mc_slot); break;
@@ -540,7 +604,7 @@ size_t mc_table_device_bytes(const mc_table *t) {
            align256(t->trans.size() * sizeof(mc_slot)) + align256(t->ctxhash.size() * sizeof(mc_slot)) +
            align256(t->sym_chars.size() * sizeof(uint32_t)) + align256(t->wordhash.size() * sizeof(mc_slot)) +
            align256(t->sym_text_off.size() * sizeof(uint32_t)) + align256(t->sym_text.size() * sizeof(uint32_t)) +
-           align256(MC_STATUS_WORDS * sizeof(uint64_t)) +
+           align256(MC_STATUS_WORDS * sizeof(uint64_t)) + align256(t->dense.size() * sizeof(mc_payload)) +
            align256(t->seg_off.size() * 4) + align256(t->seg_row.size() * 4) + align256(t->seg_len.size() * 4) +
            align256(t->labhash.size() * sizeof(mc_slot)) + align256(t->lab_off.size() * 4) +
            align256(t->lab_units.size() * 4) + align256(t->lab_cand_off.size() * 4) + align256(t->lab_cand.size() * 4) +

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Tuning experiment (GPU box): time k_sample alone on the bench model for a grid of
-MC_SAMPLE_CHAINS x MC_SAMPLE_WG_PER_CU x MC_GUIDE_FACTOR.  Each configuration runs in a child
-process (the library reads its knobs once).  Usage: exp_sample.py [chains,...] [wg,...] [gf,...]"""
+MC_SAMPLE_CHAINS x MC_SAMPLE_WG_PER_CU x MC_GUIDE_FACTOR x MC_SAMPLE_HOT_KB.  Each configuration runs in a child
+process (the library reads its knobs once).  Usage: exp_sample.py [chains,...] [wg,...] [gf,...] [hot_kb,...]"""
 import json
 import os
 import subprocess
@@ -38,16 +38,19 @@ print(json.dumps({"ms_med": ts[5], "ms_min": ts[0], "indirect_per_draw": cnt["in
 def main():
     chains = sys.argv[1].split(",") if len(sys.argv) > 1 else ["1", "2", "4"]
     wgs = sys.argv[2].split(",") if len(sys.argv) > 2 else ["8"]
-    gfs = sys.argv[3].split(",") if len(sys.argv) > 3 else ["2"]
+    gfs = sys.argv[3].split(",") if len(sys.argv) > 3 else ["4"]
+    hots = sys.argv[4].split(",") if len(sys.argv) > 4 else ["20"]
     for gf in gfs:
+      for hot in hots:
         for wg in wgs:
             for nc in chains:
-                env = dict(os.environ, MC_SAMPLE_CHAINS=nc, MC_SAMPLE_WG_PER_CU=wg, MC_GUIDE_FACTOR=gf)
+                env = dict(os.environ, MC_SAMPLE_CHAINS=nc, MC_SAMPLE_WG_PER_CU=wg, MC_GUIDE_FACTOR=gf,
+                           MC_SAMPLE_HOT_KB=hot)
                 r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=300)
                 if r.returncode != 0:
-                    print(f"chains={nc} wg={wg} gf={gf}: FAILED rc={r.returncode}\n{r.stderr[-2000:]}", flush=True)
+                    print(f"chains={nc} wg={wg} gf={gf} hot={hot}: FAILED rc={r.returncode}\n{r.stderr[-2000:]}", flush=True)
                     sys.exit(1)
-                print(f"chains={nc} wg={wg} gf={gf}: {r.stdout.strip().splitlines()[-1]}", flush=True)
+                print(f"chains={nc} wg={wg} gf={gf} hot={hot}: {r.stdout.strip().splitlines()[-1]}", flush=True)
 
 
 if __name__ == "__main__":

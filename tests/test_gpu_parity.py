@@ -293,6 +293,25 @@ def test_scoring_matches_c_oracle(big_model):
     assert 0 < int((want == 1022.0).sum()) < len(test)
 
 
+def test_scoring_hash_path_equals_dense_path(big_model):
+    """k_score<DENSE> (one gather per step) and k_score<hash> (probe + backoff chain) agree."""
+    from montecarlo_amd import _native as nv
+    from montecarlo_amd.engine import DeviceModel
+    from montecarlo_amd.tables import FlatTable
+    m, cm = big_model
+    assert len(m._flat.array(nv.ARR_DENSE)) > 0
+    flat = FlatTable(m.nwords, nv.KIND_BACKOFF, start_units=["\x00"], end_chr=m.end_chr, flags=nv.FLAG_NO_DENSE)
+    assert len(flat.array(nv.ARR_DENSE)) == 0
+    dev = DeviceModel(flat)
+    test = list(dict.fromkeys(synth.zipf_corpus(20000, oov_frac=0.03, stream=2))) + ["", "\x7f"]
+    syms, off = flat.encode_chars(test)
+    a = dev.score_ids(syms, off)
+    syms2, off2 = m._flat.encode_chars(test)
+    b = m._dev.score_ids(syms2, off2)
+    assert torch.equal(a.view(torch.int64), b.view(torch.int64))
+    assert np.array_equal(a.cpu().numpy().view(np.uint64), cm.score(test).view(np.uint64))
+
+
 def test_rank_pipeline_full_size(big_model):
     """config-2 sizes: 1e7 samples, 1e6 queries -- size-independent properties plus an
     independent device sort (torch.sort) and a CPU prefix sum on a stride."""

@@ -188,6 +188,27 @@ def test_draw_table_equals_bisect(train_char):
     assert kinds == {nv.DRAW_DIRECT, nv.DRAW_ONE, nv.DRAW_MULTI}
 
 
+def test_dense_transitions_equal_backoff_chain(train_char):
+    """The dense (row, symbol) table k_score<DENSE> gathers from holds exactly what walking the
+    parent chain with the transition hash finds (longest suffix row that lists the symbol)."""
+    for m in (BackWordsMonteCarlo(synth.as_file(train_char), splitter="", threshold=10),
+              NWordsMonteCarlo(synth.as_file(train_char), n=4, splitter="")):
+        w = CompiledWalker(m._flat)
+        dense = m._flat.array(nv.ARR_DENSE)
+        n_sym = len(m._flat.symbols)
+        assert len(dense) == len(w.state) * n_sym
+        rng = np.random.default_rng(9)
+        for row in rng.choice(len(w.state), size=150, replace=False):
+            for s in range(n_sym):
+                e = w.entry(int(row), s)
+                got = dense[int(row) * n_sym + s]
+                assert int(got["sym"]) == e
+                if e != nv.MC_NONE:
+                    assert (got["ml2p"], got["next"]) == (w.payload[e]["ml2p"], w.payload[e]["next"])
+    sub = NWordsMonteCarlo(synth.as_file(golden_lines("train_tab.txt")), n=3, splitter="\t")
+    assert len(sub._flat.array(nv.ARR_DENSE)) == 0          # sub-word alphabets keep the hash + DFS path
+
+
 def test_compile_rejects_bad_tables():
     from montecarlo_amd.lib4mc.ProbLib import expand_2d
     from montecarlo_amd.tables import FlatTable

@@ -74,6 +74,10 @@ struct DevModel {
     uint32_t n_np, kind;
 };
 
+__device__ __forceinline__ unsigned long long *status_slot(const DevModel &m) {
+    return m.status + (size_t)((blockIdx.x * 4u + (threadIdx.x >> 6)) & (MC_STATUS_SLOTS - 1)) * MC_STATUS_STRIDE;
+}
+
 struct SampleArgs {
     unsigned long long first_id, count, seed;
     const double *uniforms;  // injected mode
@@ -310,7 +314,7 @@ __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
     __syncthreads();
     if (threadIdx.x < 5 && blk_cnt[threadIdx.x]) {
         const int word = threadIdx.x < 4 ? MC_CNT_DRAWS + threadIdx.x : MC_CNT_INDIRECT;
-        atomicAdd(&m.status[word], (unsigned long long)blk_cnt[threadIdx.x]);
+        atomicAdd(&status_slot(m)[word], (unsigned long long)blk_cnt[threadIdx.x]);
     }
 }
 
@@ -338,48 +342,87 @@ __device__ __forceinline__ uint32_t find_entry(const DevModel &m, uint32_t state
 }
 
 // DENSE: the model has the resolved (row, symbol) table, a step is one 16-byte gather; otherwise
-// the (row,symbol) hash is probed along the backoff chain.
-template <bool DENSE>
+// the (row,symbol) hash is probed along the backoff chain.  A lane walks NP passwords at a time
+// (independent chains: the kernel is bound by gather latency, not by issue).
+template <bool DENSE, int NP>
 __global__ void __launch_bounds__(256) k_score(DevModel m, const uint32_t *__restrict__ syms,
                                                const unsigned long long *__restrict__ off, unsigned long long count,
                                                double *__restrict__ out) {
     unsigned int c_probe = 0, c_step = 0;
-    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < count;
-         t += (unsigned long long)gridDim.x * blockDim.x) {
-        const unsigned long long a = off[t], b = off[t + 1];
-        uint32_t state = m.start_state;
-        double acc = 0.0;
-        bool ok = true;
-        uint32_t s_next = a < b ? syms[a] : m.end_sym;
-        for (unsigned long long j = a; j <= b; ++j) {
-            const uint32_t s = s_next;
-            // the next symbol is requested before this step's gather, so the two are in flight together
-            s_next = j + 1 < b ? syms[j + 1] : m.end_sym;
-            if (s >= m.n_sym || state == MC_NONE) {
-                ok = false;
-                break;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long t0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t0 < count;
+         t0 += stride * NP) {
+        unsigned long long j[NP], b[NP];
+        uint32_t state[NP], s_next[NP];
+        double acc[NP];
+        bool run[NP], ok[NP];
+        bool any = false;
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+            const unsigned long long t = t0 + c * stride;
+            run[c] = t < count;
+            ok[c] = true;
+            j[c] = b[c] = 0;
+            if (run[c]) {
+                j[c] = off[t];
+                b[c] = off[t + 1];
             }
-            Payload p;
-            if (DENSE) {
-                p = m.dense[(size_t)state * m.n_sym + s];
-                ++c_probe;
-                if (p.sym == MC_NONE) {
-                    ok = false;
-                    break;
-                }
-            } else {
-                const uint32_t e = find_entry(m, state, s, c_probe);
-                if (e == MC_NONE) {
-                    ok = false;
-                    break;
-                }
-                p = m.payload[e];
-            }
-            acc += p.ml2p;
-            state = p.next;
-            ++c_step;
+            state[c] = m.start_state;
+            acc[c] = 0.0;
+            s_next[c] = (run[c] && j[c] < b[c]) ? syms[j[c]] : m.end_sym;
+            any |= run[c];
         }
-        out[t] = (ok && acc < 1022.0) ? acc : 1022.0;
+        while (any) {
+            Payload p[NP];
+            bool step[NP];
+            uint32_t s[NP];
+            // symbols of this step; the next ones are requested before this step's gathers, so that
+            // they are all in flight together
+#pragma unroll
+            for (int c = 0; c < NP; ++c) {
+                s[c] = s_next[c];
+                s_next[c] = (run[c] && j[c] + 1 < b[c]) ? syms[j[c] + 1] : m.end_sym;
+                step[c] = run[c];
+                if (run[c] && (s[c] >= m.n_sym || state[c] == MC_NONE)) {
+                    ok[c] = false;
+                    run[c] = step[c] = false;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NP; ++c) {
+                if (!step[c]) continue;
+                if (DENSE) {
+                    p[c] = m.dense[(size_t)state[c] * m.n_sym + s[c]];
+                    ++c_probe;
+                } else {
+                    const uint32_t e = find_entry(m, state[c], s[c], c_probe);
+                    p[c] = e == MC_NONE ? Payload{0.0, MC_NONE, MC_NONE} : m.payload[e];
+                    if (e != MC_NONE) p[c].sym = e;
+                }
+            }
+            any = false;
+#pragma unroll
+            for (int c = 0; c < NP; ++c) {
+                if (step[c]) {
+                    if (p[c].sym == MC_NONE) {  // no suffix row lists the symbol
+                        ok[c] = false;
+                        run[c] = false;
+                    } else {
+                        acc[c] += p[c].ml2p;
+                        state[c] = p[c].next;
+                        ++c_step;
+                        if (j[c] == b[c]) run[c] = false;  // that was the end symbol
+                        ++j[c];
+                    }
+                }
+                any |= run[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+            const unsigned long long t = t0 + c * stride;
+            if (t < count) out[t] = (ok[c] && acc[c] < 1022.0) ? acc[c] : 1022.0;
+        }
     }
     // one atomic per wave
     for (int o = 32; o > 0; o >>= 1) {
@@ -387,8 +430,8 @@ __global__ void __launch_bounds__(256) k_score(DevModel m, const uint32_t *__res
         c_step += __shfl_down(c_step, o);
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&m.status[MC_CNT_SCORE_PROBES], (unsigned long long)c_probe);
-        atomicAdd(&m.status[MC_CNT_SCORE_STEPS], (unsigned long long)c_step);
+        atomicAdd(&status_slot(m)[MC_CNT_SCORE_PROBES], (unsigned long long)c_probe);
+        atomicAdd(&status_slot(m)[MC_CNT_SCORE_STEPS], (unsigned long long)c_step);
     }
 }
 
@@ -507,9 +550,9 @@ __global__ void __launch_bounds__(256) k_score_words(DevModel m, WordsArgs a) {
         c_long += __shfl_down(c_long, o);
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&m.status[MC_CNT_SCORE_PROBES], (unsigned long long)c_probe);
-        atomicAdd(&m.status[MC_CNT_SCORE_STEPS], (unsigned long long)c_step);
-        if (c_long) atomicAdd(&m.status[MC_CNT_SCORE_TOO_LONG], (unsigned long long)c_long);
+        atomicAdd(&status_slot(m)[MC_CNT_SCORE_PROBES], (unsigned long long)c_probe);
+        atomicAdd(&status_slot(m)[MC_CNT_SCORE_STEPS], (unsigned long long)c_step);
+        if (c_long) atomicAdd(&status_slot(m)[MC_CNT_SCORE_TOO_LONG], (unsigned long long)c_long);
     }
 }
 
@@ -608,10 +651,10 @@ __global__ void __launch_bounds__(256) k_sample_bpe(DevModel m, SampleArgs a) {
         c_indirect += __shfl_down(c_indirect, o);
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&m.status[MC_CNT_DRAWS], (unsigned long long)c_draws);
-        atomicAdd(&m.status[MC_CNT_PROBES], (unsigned long long)c_probes);
-        atomicAdd(&m.status[MC_CNT_INDIRECT], (unsigned long long)c_indirect);
-        if (c_fail) atomicAdd(&m.status[MC_CNT_FAILED], (unsigned long long)c_fail);
+        atomicAdd(&status_slot(m)[MC_CNT_DRAWS], (unsigned long long)c_draws);
+        atomicAdd(&status_slot(m)[MC_CNT_PROBES], (unsigned long long)c_probes);
+        atomicAdd(&status_slot(m)[MC_CNT_INDIRECT], (unsigned long long)c_indirect);
+        if (c_fail) atomicAdd(&status_slot(m)[MC_CNT_FAILED], (unsigned long long)c_fail);
     }
 }
 
@@ -730,8 +773,8 @@ __global__ void __launch_bounds__(256) k_score_bpe(DevModel m, const uint32_t *_
         c_step += __shfl_down(c_step, o);
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&m.status[MC_CNT_SCORE_PROBES], (unsigned long long)c_probe);
-        atomicAdd(&m.status[MC_CNT_SCORE_STEPS], (unsigned long long)c_step);
+        atomicAdd(&status_slot(m)[MC_CNT_SCORE_PROBES], (unsigned long long)c_probe);
+        atomicAdd(&status_slot(m)[MC_CNT_SCORE_STEPS], (unsigned long long)c_step);
     }
 }
 
@@ -814,7 +857,7 @@ extern "C" int mc_model_upload(const mc_table *t, int device, mc_model **out) {
     d.n_np = (uint32_t)t->np_len.size();
     d.kind = t->kind;
     d.status = (unsigned long long *)p;
-    HIP_TRY(hipMemset(d.status, 0, MC_STATUS_WORDS * sizeof(uint64_t)));
+    HIP_TRY(hipMemset(d.status, 0, (size_t)MC_STATUS_SLOTS * MC_STATUS_STRIDE * sizeof(uint64_t)));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipGetLastError());
     d.trans_mask = t->trans.size() - 1;
@@ -845,11 +888,14 @@ extern "C" int mc_model_check(mc_model *m, void *stream, uint64_t counters[8]) {
         mc_set_error("mc_model_check: null model");
         return MC_ERR_ARG;
     }
-    uint64_t host[MC_STATUS_WORDS];
+    static thread_local uint64_t slots[MC_STATUS_SLOTS * MC_STATUS_STRIDE];
+    uint64_t host[MC_STATUS_WORDS] = {0};
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(hipMemcpyAsync(host, m->dev.status, sizeof host, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemsetAsync(m->dev.status, 0, sizeof host, s));
+    HIP_TRY(hipMemcpyAsync(slots, m->dev.status, sizeof slots, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemsetAsync(m->dev.status, 0, sizeof slots, s));
     HIP_TRY(hipStreamSynchronize(s));
+    for (int k = 0; k < MC_STATUS_SLOTS; ++k)
+        for (int w = 0; w < MC_STATUS_WORDS; ++w) host[w] += slots[k * MC_STATUS_STRIDE + w];
     if (counters) std::memcpy(counters, host, sizeof host);
     if (host[MC_CNT_SCORE_TOO_LONG]) {
         mc_set_error("%llu password(s) were longer than the max_len given to mc_score_words",
@@ -954,12 +1000,17 @@ extern "C" int mc_score(mc_model *m, const uint32_t *syms, const uint64_t *off, 
     }
     unsigned long long want = (count + 255) / 256, cap = (unsigned long long)m->n_cu * 8;
     dim3 g((unsigned)(want < cap ? want : cap)), b(256);
-    if (m->dev.dense)
-        hipLaunchKernelGGL(k_score<true>, g, b, 0, (hipStream_t)stream, m->dev, syms, (const unsigned long long *)off,
-                           (unsigned long long)count, out_ml2p);
-    else
-        hipLaunchKernelGGL(k_score<false>, g, b, 0, (hipStream_t)stream, m->dev, syms,
-                           (const unsigned long long *)off, (unsigned long long)count, out_ml2p);
+    static const int env_np = getenv("MC_SCORE_CHAINS") ? atoi(getenv("MC_SCORE_CHAINS")) : 2;
+    const unsigned long long *o64 = (const unsigned long long *)off;
+    hipStream_t st = (hipStream_t)stream;
+    if (m->dev.dense) {
+        if (env_np == 1) hipLaunchKernelGGL((k_score<true, 1>), g, b, 0, st, m->dev, syms, o64, count, out_ml2p);
+        else if (env_np == 4) hipLaunchKernelGGL((k_score<true, 4>), g, b, 0, st, m->dev, syms, o64, count, out_ml2p);
+        else hipLaunchKernelGGL((k_score<true, 2>), g, b, 0, st, m->dev, syms, o64, count, out_ml2p);
+    } else {
+        if (env_np == 1) hipLaunchKernelGGL((k_score<false, 1>), g, b, 0, st, m->dev, syms, o64, count, out_ml2p);
+        else hipLaunchKernelGGL((k_score<false, 2>), g, b, 0, st, m->dev, syms, o64, count, out_ml2p);
+    }
     HIP_TRY(hipGetLastError());
     return MC_OK;
 }

@@ -6,6 +6,11 @@
 #include "../../include/mi355mc.h"
 
 #define MC_STATUS_WORDS 8
+// The counters are kept as MC_STATUS_SLOTS copies, one 128-byte line each: a wave adds to the copy its
+// (workgroup, wave) number selects and mc_model_check sums the copies.  Thousands of atomics on ONE
+// address serialise at the memory side (measured: 16k of them cost 0.18 ms, 3/4 of k_score's time).
+#define MC_STATUS_SLOTS 256
+#define MC_STATUS_STRIDE 16
 // status/counter words kept in device memory per model
 enum {
     MC_CNT_DRAWS = 0,      // uniforms consumed

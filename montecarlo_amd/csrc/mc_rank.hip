@@ -36,7 +36,7 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 
 constexpr int SORT_THREADS = 256;
-constexpr int SORT_ITEMS = 16;
+constexpr int SORT_ITEMS = 32;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 4096 keys per tile
 // look-back word of (tile, digit): 2 flag bits + count
 constexpr unsigned long long LB_LOCAL = 1ull << 62;  // count of this tile alone
@@ -44,6 +44,7 @@ constexpr unsigned long long LB_INCL = 2ull << 62;   // count of this tile and e
 constexpr unsigned long long LB_MASK = (1ull << 62) - 1;
 constexpr unsigned int LB_SPIN_LIMIT = 1u << 24;     // a bound, not a protocol: see k_onesweep
 constexpr int LB_WINDOW = 8;                         // predecessors read per look-back step
+constexpr int HIST_COPIES = 4, HIST_PITCH = 8 * 256 + 1;
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
@@ -70,30 +71,54 @@ __device__ __forceinline__ u32 digit_of(u64 k, int pass) { return (u32)(k >> (8 
 
 // ---- all 8 digit histograms in one read ------------------------------------------------------
 __global__ void __launch_bounds__(256) k_hist_all(const u64 *__restrict__ keys, u64 n, u32 *__restrict__ hist) {
-    __shared__ u32 h[8 * 256];
-    for (int i = threadIdx.x; i < 8 * 256; i += blockDim.x) h[i] = 0;
+    // HIST_COPIES copies of the 8 x 256 bins, lane l adds to copy l % HIST_COPIES: sampled keys repeat
+    // (one password drawn many times, few exponent values), and lanes adding to one LDS word serialise.
+    // Copies are HIST_PITCH words apart so that one bin's copies fall into different banks.
+    __shared__ u32 hc[HIST_COPIES * HIST_PITCH];
+    for (int i = threadIdx.x; i < HIST_COPIES * HIST_PITCH; i += blockDim.x) hc[i] = 0;
+    u32 *h = hc + (threadIdx.x % HIST_COPIES) * HIST_PITCH;
     __syncthreads();
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
-        const u64 k = keys[i];
-        const u64 first = __shfl(k, __ffsll((long long)__ballot(1)) - 1);
-        const u64 diff = k ^ first;
-        const u32 lanes = __popcll(__ballot(1));
-        const bool leader = __popcll(__ballot(1) & ((1ull << (threadIdx.x & 63)) - 1ull)) == 0;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    // four keys per lane and round, their loads issued together; whole waves stay in the loop so the
+    // ballots see every lane (a lane past the end holds no key)
+    for (u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x; i0 - threadIdx.x % 64 < n; i0 += 4 * stride) {
+        u64 k[4];
+        bool have[4];
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            // a digit the whole wave agrees on (sign/exponent bytes; runs of one repeated password)
-            // costs one LDS add, not 64 colliding ones
-            const bool same = __ballot(((diff >> (8 * p)) & 255ull) != 0) == 0;
-            if (same) {
-                if (leader) atomicAdd(&h[p * 256 + digit_of(k, p)], lanes);
-            } else {
-                atomicAdd(&h[p * 256 + digit_of(k, p)], 1u);
+        for (int r = 0; r < 4; ++r) {
+            const u64 i = i0 + r * stride;
+            have[r] = i < n;
+            k[r] = have[r] ? keys[i] : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const u64 mask = __ballot(have[r]);
+            if (mask == 0) continue;
+            const u64 first = __shfl(k[r], __ffsll((long long)mask) - 1);
+            const u64 diff = have[r] ? (k[r] ^ first) : 0;
+            const u32 lanes = __popcll(mask);
+            const bool leader = have[r] && __popcll(mask & ((1ull << (threadIdx.x & 63)) - 1ull)) == 0;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                // a digit the whole wave agrees on (sign/exponent bytes; runs of one repeated password)
+                // costs one LDS add, not 64 colliding ones
+                const bool same = __ballot(((diff >> (8 * p)) & 255ull) != 0) == 0;
+                if (same) {
+                    if (leader) atomicAdd(&h[p * 256 + digit_of(k[r], p)], lanes);
+                } else if (have[r]) {
+                    atomicAdd(&h[p * 256 + digit_of(k[r], p)], 1u);
+                }
             }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 8 * 256; i += blockDim.x)
-        if (h[i]) atomicAdd(&hist[i], h[i]);
+    // (few workgroups: every global bin takes one atomic per workgroup, and atomics on one address
+    // serialise at ~11 ns each)
+    for (int i = threadIdx.x; i < 8 * 256; i += blockDim.x) {
+        u32 v = 0;
+        for (int c = 0; c < HIST_COPIES; ++c) v += hc[c * HIST_PITCH + i];
+        if (v) atomicAdd(&hist[i], v);
+    }
 }
 
 // one workgroup: which passes do anything, and which buffer each reads/writes
@@ -434,7 +459,9 @@ extern "C" int mc_rank_build(const double *keys_in, uint64_t n, uint64_t n_globa
     {
         u64 want = (n + 255) / 256;
         u32 g = (u32)(want < 2048 ? want : 2048);
-        hipLaunchKernelGGL(k_hist_all, dim3(g), dim3(256), 0, s, in, (u64)n, ws.hist);
+        u64 hwant = (n + 2047) / 2048;
+        u32 gh = (u32)(hwant < 1024 ? (hwant ? hwant : 1) : 1024);
+        hipLaunchKernelGGL(k_hist_all, dim3(gh), dim3(256), 0, s, in, (u64)n, ws.hist);
         hipLaunchKernelGGL(k_plan, dim3(1), dim3(256), 0, s, ws.hist, (u64)n, ws.plan);
         hipLaunchKernelGGL(k_copy_if_unsorted, dim3(g), dim3(256), 0, s, ws.plan, in, A, (u64)n);
     }

@@ -604,7 +604,7 @@ size_t mc_table_device_bytes(const mc_table *t) {
            align256(t->trans.size() * sizeof(mc_slot)) + align256(t->ctxhash.size() * sizeof(mc_slot)) +
            align256(t->sym_chars.size() * sizeof(uint32_t)) + align256(t->wordhash.size() * sizeof(mc_slot)) +
            align256(t->sym_text_off.size() * sizeof(uint32_t)) + align256(t->sym_text.size() * sizeof(uint32_t)) +
-           align256(MC_STATUS_WORDS * sizeof(uint64_t)) + align256(t->dense.size() * sizeof(mc_payload)) +
+           align256((size_t)MC_STATUS_SLOTS * MC_STATUS_STRIDE * sizeof(uint64_t)) + align256(t->dense.size() * sizeof(mc_payload)) +
            align256(t->seg_off.size() * 4) + align256(t->seg_row.size() * 4) + align256(t->seg_len.size() * 4) +
            align256(t->labhash.size() * sizeof(mc_slot)) + align256(t->lab_off.size() * 4) +
            align256(t->lab_units.size() * 4) + align256(t->lab_cand_off.size() * 4) + align256(t->lab_cand.size() * 4) +

@@ -63,18 +63,26 @@ def main():
     ap.add_argument("--train-lines", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="score on the main stream instead of overlapping it")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="rehearsal of the multi-rank control flow on a 1-GPU box: every rank uses cuda:0 and the "
+                         "collective runs over gloo (the printed numbers mean nothing)")
     ap.add_argument("--cpu-samples", type=int, default=300_000)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rehearse_on_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     # ---------------- model + inputs (untimed) ----------------
@@ -125,7 +133,7 @@ def main():
             main_stream.wait_event(marks[4])
         marks[5].record()
         rk.query(t_ml2p, out_pos=q_pos, out_cnt=q_cnt)
-        mcd.combine_partials(q_pos, q_cnt)                  # one RCCL all-reduce each; no-op on one GPU
+        mcd.combine_positions(q_pos)                        # ONE RCCL all-reduce (8 MB); no-op on one GPU
         marks[6].record()
         if timed:
             ev["sample"].append((marks[0], marks[1]))

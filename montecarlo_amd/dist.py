@@ -5,8 +5,9 @@ positions[idx-1] = sum over samples j with ml2p_j <= x of 2^(ml2p_j - log2 N)
 disjoint sample shards as long as every shard weights with the GLOBAL N.  Each
 rank draws its own sample ids on the shared Philox stream, sorts and scans
 locally and answers every test password locally; ONE all-reduce (SUM) of the
-fp64 partial sums (and of the int64 counts, which decide the reference's
-``idx > 0`` branch) finishes the estimate.  Samples never move between GPUs.
+fp64 partial sums finishes the estimate (`combine_positions`; the int64 counts that
+decide the reference's ``idx > 0`` branch can be summed too, `combine_partials`, but
+are implied by the positions).  Samples never move between GPUs.
 
 Backend: torch.distributed -- "nccl" is RCCL over xGMI on the GPU box, "gloo" in
 the CPU tests.  T <= 1e6 test passwords is 8 MB: latency-bound, one bucket.
@@ -33,6 +34,20 @@ def combine_partials(pos: torch.Tensor, cnt: torch.Tensor, group=None) -> Tuple[
         dist.all_reduce(pos, op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
     return pos, cnt
+
+
+def combine_positions(pos: torch.Tensor, group=None) -> torch.Tensor:
+    """The one collective of the hot path: sum the per-shard partial positions in place.  The counts
+    need not travel: every weight 2^(ml2p - log2 N) is positive, so "some shard holds a sample
+    <= x" (the reference's ``idx > 0``) is the same as "the summed position is > 0"."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(pos, op=dist.ReduceOp.SUM, group=group)
+    return pos
+
+
+def estimates_from_positions(pos: torch.Tensor) -> torch.Tensor:
+    """``positions[idx-1] if idx > 0 else 1`` from the summed positions alone."""
+    return torch.where(pos > 0, pos, torch.ones_like(pos))
 
 
 def estimates(pos: torch.Tensor, cnt: torch.Tensor) -> torch.Tensor:

@@ -48,8 +48,9 @@ class MonteCarloLib:
         x = torch.as_tensor(numpy.asarray(xs, dtype=numpy.float64)).to(self.__rank.tdev)
         pos, cnt = self.__rank.query(x.contiguous())
         if self.__group is not None:
+            # every weight is positive: the summed position is > 0 exactly when some shard counted a sample
             torch.distributed.all_reduce(pos, group=self.__group)
-            torch.distributed.all_reduce(cnt, group=self.__group)
+            cnt = (pos > 0).to(torch.int64)
         return pos.cpu().numpy(), cnt.cpu().numpy()
 
     def ml2p2rank(self, minus_log_prob):

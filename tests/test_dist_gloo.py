@@ -36,8 +36,10 @@ def _worker(rank, world, port, n_global, out_dir):
     x = np.linspace(0.0, 60.0, 501)
     p, c = c_oracle.rank_query(srt, pos, x)
     tp, tc = torch.from_numpy(p.copy()), torch.from_numpy(c.astype(np.int64))
+    only_pos = mcd.estimates_from_positions(mcd.combine_positions(tp.clone()))
     mcd.combine_partials(tp, tc)
     est = mcd.estimates(tp, tc)
+    assert torch.equal(est, only_pos)                          # the counts are implied by the positions
     if rank == 0:
         np.save(os.path.join(out_dir, "est.npy"), est.numpy())
         np.save(os.path.join(out_dir, "cnt.npy"), tc.numpy())

@@ -7,8 +7,8 @@
 //             upfront kernel builds all 8 digit histograms; passes whose digit is constant over
 //             the whole input (the sign/exponent bytes, typically) are skipped and the
 //             ping-pong is planned so the last pass lands in keys_sorted.  Each active pass is
-//             ONE kernel that reads every key once and writes it once: a workgroup takes the
-//             next tile (ticket), ranks its 4096 keys by digit (wave ballots), publishes the
+//             ONE kernel that reads every key once and writes it once: a (persistent) workgroup
+//             takes its next tile, ranks its 6144 keys by digit (wave ballots), publishes the
 //             tile's digit counts, obtains the counts of all earlier tiles by decoupled
 //             look-back over the published words, and scatters through LDS so global writes
 //             are digit-contiguous runs.
@@ -36,7 +36,7 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 
 constexpr int SORT_THREADS = 256;
-constexpr int SORT_ITEMS = 32;
+constexpr int SORT_ITEMS = 24;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 4096 keys per tile
 // look-back word of (tile, digit): 2 flag bits + count
 constexpr unsigned long long LB_LOCAL = 1ull << 62;  // count of this tile alone
@@ -61,7 +61,7 @@ struct Plan {
 
 struct SortWs {
     u64 *temp;        // [n] second key buffer
-    u32 *hist;        // [8][256], then ticket[8], then error flag
+    u32 *hist;        // [8][256], 8 spare words, then the error flag
     u64 *lookback;    // [2][tiles][256]
     Plan *plan;
     double *partials; // [scan blocks]
@@ -162,15 +162,19 @@ __global__ void __launch_bounds__(256) k_copy_if_unsorted(const Plan *__restrict
 }
 
 // ---- one radix pass, one kernel (onesweep) -------------------------------------------------------
-// Tiles are handed out by ticket, so every tile a workgroup waits for belongs to a workgroup that
-// started earlier and never waits for a later one: the look-back cannot deadlock.  The spin is
-// nevertheless bounded; if the bound is ever hit the error word is set and k_positions poisons the
-// output with NaN (loud, not a hang).  Look-back words are written and read with agent-scope
-// atomics (the per-XCD L2s are not coherent with each other); nothing else crosses workgroups.
+// Persistent workgroups: the grid is no larger than what the GPU holds at once (the host sizes it
+// from the kernel's occupancy), and workgroup g takes tiles g, g + G, g + 2G, ...  A tile only ever
+// waits for LOWER tiles; the lowest unfinished tile belongs to a workgroup that is resident or will
+// be made resident without anyone else finishing, and it waits for nothing: the look-back cannot
+// deadlock whatever order the hardware dispatches in.  (A ticket counter would give the same
+// guarantee, but 2,441 atomics on one address cost 13 us per pass: same-address atomics serialise
+// at ~11 ns each.)  The spin is nevertheless bounded; if the bound is ever hit the error word is
+// set and k_positions poisons the output with NaN (loud, not a hang).  Look-back words are written
+// and read with agent-scope atomics (the per-XCD L2s are not coherent with each other); nothing
+// else crosses workgroups.
 __global__ void __launch_bounds__(SORT_THREADS) k_onesweep(const Plan *__restrict__ plan, int pass, const u64 *in,
                                                             u64 *a, u64 *b, u64 n, u32 tiles,
-                                                            const u32 *__restrict__ hist, u32 *ticket, u32 *err,
-                                                            u64 *lookback) {
+                                                            const u32 *__restrict__ hist, u32 *err, u64 *lookback) {
     if (plan->skip[pass]) return;
     const u64 *src = pick_src(plan->src[pass], in, a, b);
     u64 *dst = plan->dst[pass] == 1 ? a : b;
@@ -182,12 +186,10 @@ __global__ void __launch_bounds__(SORT_THREADS) k_onesweep(const Plan *__restric
     __shared__ u32 tile_off[256];  // exclusive scan of the tile's digit counts
     __shared__ u32 wave_sum[4];
     __shared__ u32 wave_below[4];
-    __shared__ u32 tile_s;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) tile_s = atomicAdd(&ticket[pass], 1u);
+    for (u32 tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     for (int w = 0; w < 4; ++w) wcnt[w][tid] = 0;
-    __syncthreads();
-    const u32 tile = tile_s;
+    __syncthreads();  // (also: every wave has left the previous tile's write-out)
     const u64 t0 = (u64)tile * SORT_TILE;
     const u32 tile_n = (u32)min((u64)SORT_TILE, n - t0);
     lb_next[(u64)tile * 256 + tid] = 0;  // the next active pass starts from clean words
@@ -305,6 +307,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_onesweep(const Plan *__restric
         const u32 d = digit_of(k, pass);
         dst[base[d] + (j - tile_off[d])] = k;
     }
+    }  // next tile of this workgroup
 }
 
 // ---- positions: prefix sum of 2^(key - log2 n_global) ------------------------------------------
@@ -405,8 +408,33 @@ __global__ void __launch_bounds__(256) k_query(const double *__restrict__ keys, 
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// Workgroups of k_onesweep the current device holds at once (its look-back relies on the whole grid
+// being resident): the occupancy API's answer, capped by what the kernel's LDS allows.
+int onesweep_resident_workgroups(int *out) {
+    static int cached[64] = {0};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (!cached[dev]) {
+        int per_cu = 0, n_cu = 0;
+        hipFuncAttributes attr;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_onesweep, SORT_THREADS, 0));
+        HIP_TRY(hipFuncGetAttributes(&attr, (const void *)k_onesweep));
+        HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        const int by_lds = attr.sharedSizeBytes ? (int)(160 * 1024 / attr.sharedSizeBytes) : per_cu;
+        if (by_lds < per_cu) per_cu = by_lds;
+        if (per_cu < 1 || n_cu < 1) {
+            mc_set_error("k_onesweep does not fit a compute unit (occupancy %d, %d CUs)", per_cu, n_cu);
+            return MC_ERR_HIP;
+        }
+        cached[dev] = per_cu * n_cu;
+    }
+    *out = cached[dev];
+    return MC_OK;
+}
+
 u32 sort_tiles(u64 n) { return (u32)((n + SORT_TILE - 1) / SORT_TILE); }
-constexpr size_t HIST_WORDS = 8 * 256 + 8 + 8;  // histograms, tickets, error word (+pad)
+constexpr size_t HIST_WORDS = 8 * 256 + 8 + 8;  // histograms, spare, error word (+pad)
 u32 scan_blocks(u64 n) {
     u64 tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     return (u32)(tiles < (u64)SCAN_MAX_BLOCKS ? (tiles ? tiles : 1) : SCAN_MAX_BLOCKS);
@@ -450,11 +478,11 @@ extern "C" int mc_rank_build(const double *keys_in, uint64_t n, uint64_t n_globa
     ws.plan = (Plan *)p;
     p += align256(sizeof(Plan));
     ws.partials = (double *)p;
-    u32 *ticket = ws.hist + 8 * 256, *err = ws.hist + 8 * 256 + 8;
+    u32 *err = ws.hist + 8 * 256 + 8;
 
     const u64 *in = (const u64 *)keys_in;
     u64 *A = (u64 *)keys_sorted, *B = ws.temp;
-    // histograms, tickets, error word and both look-back regions are contiguous: one clear
+    // histograms, error word and both look-back regions are contiguous: one clear
     HIP_TRY(hipMemsetAsync(ws.hist, 0, align256(HIST_WORDS * sizeof(u32)) + lb_bytes, s));
     {
         u64 want = (n + 255) / 256;
@@ -465,9 +493,15 @@ extern "C" int mc_rank_build(const double *keys_in, uint64_t n, uint64_t n_globa
         hipLaunchKernelGGL(k_plan, dim3(1), dim3(256), 0, s, ws.hist, (u64)n, ws.plan);
         hipLaunchKernelGGL(k_copy_if_unsorted, dim3(g), dim3(256), 0, s, ws.plan, in, A, (u64)n);
     }
+    int resident = 0;
+    {
+        int rc = onesweep_resident_workgroups(&resident);
+        if (rc != MC_OK) return rc;
+    }
+    const u32 os_grid = tiles < (u32)resident ? tiles : (u32)resident;
     for (int pass = 0; pass < 8; ++pass)
-        hipLaunchKernelGGL(k_onesweep, dim3(tiles), dim3(SORT_THREADS), 0, s, ws.plan, pass, in, A, B, (u64)n, tiles,
-                           (const u32 *)ws.hist, ticket, err, ws.lookback);
+        hipLaunchKernelGGL(k_onesweep, dim3(os_grid), dim3(SORT_THREADS), 0, s, ws.plan, pass, in, A, B, (u64)n, tiles,
+                           (const u32 *)ws.hist, err, ws.lookback);
     // positions
     const double logn = std::log2((double)n_global);
     const u32 sb = scan_blocks(n);

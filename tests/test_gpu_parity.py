@@ -349,7 +349,7 @@ def test_rank_pipeline_full_size(big_model):
 def test_rank_edge_sizes():
     dev = torch.device("cuda")
     g = torch.Generator(device="cpu").manual_seed(3)
-    for n in (1, 2, 63, 64, 65, 4095, 4096, 4097, 100001):
+    for n in (1, 2, 63, 64, 65, 4095, 4096, 4097, 6143, 6144, 6145, 12289, 100001):
         keys = (torch.rand(n, generator=g, dtype=torch.float64) * 60).to(dev)
         if n > 10:
             keys[n // 2:] = keys[: n - n // 2].clone()          # duplicates

@@ -83,7 +83,7 @@ typedef struct mc_model_desc {
     uint32_t min_len;       /* accept a sample iff pwd_len >= min_len (nwords_simulator.py:101; v2 `> 3`) */
     uint32_t max_len;       /* restart when pwd_len >= max_len (nwords_simulator.py:112): 256 */
     uint32_t flags;         /* MC_FLAG_* */
-    uint32_t guide_factor;  /* draw-table buckets per row ~ guide_factor * row length, rounded up to 2^k (0 -> 4) */
+    uint32_t guide_factor;  /* draw-table budget: ~guide_factor * n_ent buckets, shared out by expected visits (0 -> 2) */
     /* text of every transition symbol as Unicode code points (symbol s = sym_text[sym_text_off[s] ..
      * sym_text_off[s+1])): what `left in self.words` / `left in row` compare against in _structures
      * (nwords_simulator.py:42-45).  NULL: mc_score_words is unavailable for the model. */

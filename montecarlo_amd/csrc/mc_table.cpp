@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <string>
 
@@ -270,7 +271,7 @@ extern "C" int mc_table_compile(const mc_model_desc *d, mc_table **out) {
         delete t;
         return MC_ERR_TABLE;
     }
-    uint32_t gf = d->guide_factor ? d->guide_factor : 4;
+    uint32_t gf = d->guide_factor ? d->guide_factor : 2;
     t->state.resize(d->n_ctx);
     t->cum.assign(d->ent_cum, d->ent_cum + d->n_ent);
     t->payload.resize(d->n_ent);
@@ -309,20 +310,8 @@ extern "C" int mc_table_compile(const mc_model_desc *d, mc_table **out) {
                 }
             }
         }
-        uint32_t gbits = 0;
-        if (L > 1) {
-            uint64_t K = pow2ceil((uint64_t)gf * L);
-            while ((1ull << gbits) < K) ++gbits;
-            if (gbits > 16) gbits = 16;
-        }
-        st.gbits = gbits;
+        st.gbits = 0;      // decided below from the row's expected visits
         st.guide_off = 0;  // assigned below, hottest rows first
-        n_buckets += 1ull << gbits;
-        if (n_buckets >= 0xFFFFFFF0ull) {
-            mc_set_error("draw table exceeds 2^32 buckets; lower guide_factor");
-            delete t;
-            return MC_ERR_TABLE;
-        }
         for (uint64_t e = e0; e < e1; ++e) {
             uint32_t s = d->ent_sym[e];
             seq.assign(d->ctx_units + ca, d->ctx_units + ca + cn);
@@ -337,12 +326,12 @@ extern "C" int mc_table_compile(const mc_model_desc *d, mc_table **out) {
             p.sym = s | (s == d->end_sym ? 0x80000000u : 0u);
         }
     }
-    // ---- bucket placement: rows in descending order of expected visits per bucket, so that the
-    // head of the draw table is what the sampling kernel keeps in LDS.  Visits are propagated from
-    // the start row along the next-state links (restarts ignored): an estimate that only affects
-    // speed, never results.
+    // ---- expected visits of every row per sampled string: propagated from the start row along the
+    // next-state links (restarts ignored).  An estimate that only steers speed, never results: it
+    // decides how many buckets a row gets and where they are placed.
+    std::vector<double> visits(d->n_ctx, 0.0);
     {
-        std::vector<double> visits(d->n_ctx, 0.0), cur(d->n_ctx, 0.0), nxt(d->n_ctx, 0.0);
+        std::vector<double> cur(d->n_ctx, 0.0), nxt(d->n_ctx, 0.0);
         if (t->start_state != MC_NONE && !bpe) {
             cur[t->start_state] = 1.0;
             for (int step = 0; step < 48; ++step) {
@@ -368,7 +357,63 @@ extern "C" int mc_table_compile(const mc_model_desc *d, mc_table **out) {
                 cur.swap(nxt);
                 if (alive < 1e-9) break;
             }
+        } else if (bpe) {
+            // the grammar row once per string; a terminal row once per segment that names it
+            visits[0] = 1.0;
+            const mc_state_rec &g = t->state[0];
+            double prev = 0.0;
+            for (uint32_t j = 0; j < g.len; ++j) {
+                const double pj = (t->cum[j] - prev) / g.total;
+                prev = t->cum[j];
+                for (uint32_t k = d->seg_off[j]; k < d->seg_off[j + 1]; ++k)
+                    if (d->seg_row[k] != MC_NONE) visits[d->seg_row[k]] += pj;
+            }
         }
+    }
+    // ---- buckets per row.  A bucket that straddles a threshold costs the sampling kernel a second
+    // dependent gather, and a row of L entries has at most L-1 such buckets however many it owns: the
+    // share of a row's draws that pay is ~ (L-1) / buckets.  Minimising sum(visits * (L-1) / buckets)
+    // under a budget of guide_factor * n_ent buckets gives buckets ~ sqrt(visits * (L-1)); every row
+    // keeps at least L buckets (rounded up to 2^k).
+    {
+        const double budget = (double)gf * (double)d->n_ent;
+        auto total_for = [&](double K) {
+            double tot = 0.0;
+            for (uint32_t r = 0; r < d->n_ctx; ++r) {
+                const uint32_t L = t->state[r].len;
+                if (L <= 1) { tot += 1.0; continue; }
+                double want = std::max((double)L, K * std::sqrt(visits[r] * (double)(L - 1)));
+                tot += (double)pow2ceil((uint64_t)std::min(want, 1048576.0));
+            }
+            return tot;
+        };
+        double lo = 0.0, hi = 1.0;
+        while (total_for(hi) < budget && hi < 1e12) hi *= 2.0;
+        for (int it = 0; it < 50; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if (total_for(mid) <= budget) lo = mid; else hi = mid;
+        }
+        for (uint32_t r = 0; r < d->n_ctx; ++r) {
+            const uint32_t L = t->state[r].len;
+            uint32_t gbits = 0;
+            if (L > 1) {
+                double want = std::max((double)L, lo * std::sqrt(visits[r] * (double)(L - 1)));
+                const uint64_t K = pow2ceil((uint64_t)std::min(want, 1048576.0));
+                while ((1ull << gbits) < K) ++gbits;
+                if (gbits > 20) gbits = 20;
+            }
+            t->state[r].gbits = gbits;
+            n_buckets += 1ull << gbits;
+        }
+        if (n_buckets >= 0xFFFFFFF0ull) {
+            mc_set_error("draw table exceeds 2^32 buckets; lower guide_factor");
+            delete t;
+            return MC_ERR_TABLE;
+        }
+    }
+    // ---- bucket placement: rows in descending order of expected visits per bucket, so that the
+    // head of the draw table is what the sampling kernel keeps in LDS.
+    {
         std::vector<uint32_t> order(d->n_ctx);
         for (uint32_t r = 0; r < d->n_ctx; ++r) order[r] = r;
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {

@@ -37,7 +37,7 @@ class FlatTable:
                  end_chr: str = "\x03", min_len: int = 4, max_len: int = 256, flags: int = 0,
                  minus_log_based: bool = False, unit_of_symbol=None, guide_factor: Optional[int] = None):
         if guide_factor is None:
-            guide_factor = int(os.environ.get("MC_GUIDE_FACTOR", "4"))
+            guide_factor = int(os.environ.get("MC_GUIDE_FACTOR", "2"))
         self.kind = kind
         sym_id: Dict[str, int] = {}
         symbols: List[str] = []
@@ -198,7 +198,7 @@ class BpeFlat(FlatTable):
 
     def __init__(self, grammars, terminals, converted, not_parsed, class_of, guide_factor: Optional[int] = None):
         if guide_factor is None:
-            guide_factor = int(os.environ.get("MC_GUIDE_FACTOR", "4"))
+            guide_factor = int(os.environ.get("MC_GUIDE_FACTOR", "2"))
         g_vals, g_keys, g_cum = grammars
         self.kind = nv.KIND_BPE
         self.structures = list(g_keys)

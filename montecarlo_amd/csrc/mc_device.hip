@@ -146,6 +146,7 @@ __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
 
     unsigned int c_draws = 0, c_probes = 0, c_restart = 0, c_fail = 0, c_indirect = 0;
     unsigned int local[NC];
+    uint32_t *sym_row[NC];  // where this chain's string goes (null: strings not wanted)
     uint32_t goff[NC], gbits[NC], plen[NC], nsym[NC], draw[NC];
     double acc[NC];
     bool live[NC];
@@ -155,6 +156,7 @@ __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
         local[c] = atomicAdd(&cursor, 1u);
         live[c] = local[c] < nblk;
         any |= live[c];
+        sym_row[c] = a.out_syms ? a.out_syms + (b0 + local[c]) * a.sym_stride : nullptr;
         goff[c] = m.start_draw;
         gbits[c] = m.start_gbits;
         plen[c] = nsym[c] = draw[c] = 0;
@@ -259,8 +261,7 @@ __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
                     if (plen[c] >= m.min_len) done = ok = true; else restart = true;
                 } else {
                     const uint32_t s = MC_DRAW_SYM(q[c].w3);
-                    if (a.out_syms && nsym[c] < a.sym_stride)
-                        a.out_syms[(b0 + local[c]) * a.sym_stride + nsym[c]] = s;
+                    if (sym_row[c] && nsym[c] < a.sym_stride) sym_row[c][nsym[c]] = s;
                     ++nsym[c];
                     plen[c] += MULTICHAR ? m.sym_chars[s] : 1u;
                     goff[c] = q[c].w2;
@@ -302,6 +303,7 @@ __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
                 if (a.out_draws) a.out_draws[i] = res_draws[c];
                 local[c] = atomicAdd(&cursor, 1u);
                 live[c] = local[c] < nblk;
+                if (a.out_syms) sym_row[c] = a.out_syms + (b0 + local[c]) * a.sym_stride;
             }
             any |= live[c];
         }

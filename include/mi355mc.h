@@ -203,6 +203,35 @@ typedef struct mc_slot {
     uint32_t pad;
 } mc_slot;
 
+/* ---- trainers (host only): nwords_counter (nwords/nwords_trainer.py:22-53) and backwords_counter
+ * (backwords/backwords_trainer.py:23-78) on the decoded text of the training file (UTF-8, '\n' line
+ * ends), with the reference's dict orders and fp64 arithmetic, straight into flattened rows.
+ * splitter_cp = 0: every character is a symbol (splitter ''); otherwise the one-character column
+ * separator (' ', '\t'), columns taken start4word::skip4word.  start_cp / end_cp: start_chr / end_chr. */
+typedef struct mc_trained mc_trained;
+int mc_train_nwords(const char *utf8, size_t bytes, uint32_t n, uint32_t splitter_cp, uint32_t start4word,
+                    uint32_t skip4word, uint32_t start_cp, uint32_t end_cp, mc_trained **out);
+int mc_train_backwords(const char *utf8, size_t bytes, uint32_t splitter_cp, uint32_t start4word, uint32_t skip4word,
+                       uint32_t threshold, uint32_t max_gram, uint32_t start_cp, uint32_t end_cp, mc_trained **out);
+void mc_trained_free(mc_trained *t);
+enum {
+    MC_TRAINED_CTX_OFF = 0,      /* uint32[n_ctx+1] */
+    MC_TRAINED_CTX_UNITS = 1,    /* uint32[]: symbol ids of every row's context */
+    MC_TRAINED_ROW_OFF = 2,      /* uint64[n_ctx+1] */
+    MC_TRAINED_ENT_SYM = 3,      /* uint32[n_ent] */
+    MC_TRAINED_ENT_PROB = 4,     /* double[n_ent]: the trainer's {symbol: p} values, row by row in dict order */
+    MC_TRAINED_ENT_CUM = 5,      /* double[n_ent]: expand_1d's cumulative sums (lib4mc/ProbLib.py:23) */
+    MC_TRAINED_ENT_ML2P = 6,     /* double[n_ent]: -log2 p */
+    MC_TRAINED_SYM_TEXT_OFF = 7, /* uint32[n_sym+1] */
+    MC_TRAINED_SYM_TEXT = 8,     /* uint32[]: code points of every symbol */
+    MC_TRAINED_WORD_SYM = 9,     /* uint32[]: the trainer's `words` dict, symbols in first-seen order ... */
+    MC_TRAINED_WORD_COUNT = 10   /* uint64[]: ... and their occurrence counts */
+};
+int64_t mc_trained_array(const mc_trained *t, int what, void *dst, size_t cap);
+/* mc_table_compile on the trained rows (kind MC_KIND_NGRAM with order = n-1, or MC_KIND_BACKOFF). */
+int mc_trained_compile(const mc_trained *t, uint32_t kind, uint32_t order, uint32_t min_len, uint32_t max_len,
+                       uint32_t flags, uint32_t guide_factor, mc_table **out);
+
 /* ---- device residency ---------------------------------------------------------------------*/
 /* Uploads the compiled table to GPU `device` (one hipMalloc arena). */
 int mc_model_upload(const mc_table *t, int device, mc_model **out);

@@ -26,6 +26,8 @@ FLAG_NO_DENSE = 2
  INFO_DEVICE_BYTES, INFO_MAX_ROW, INFO_KIND, INFO_MULTICHAR, INFO_START_DRAW, INFO_DIRECT_BUCKETS,
  INFO_ONE_BUCKETS, INFO_MULTI_BUCKETS) = range(16)
 DRAW_DIRECT, DRAW_ONE, DRAW_MULTI = 0, 1, 2
+(TRAINED_CTX_OFF, TRAINED_CTX_UNITS, TRAINED_ROW_OFF, TRAINED_ENT_SYM, TRAINED_ENT_PROB, TRAINED_ENT_CUM,
+ TRAINED_ENT_ML2P, TRAINED_SYM_TEXT_OFF, TRAINED_SYM_TEXT, TRAINED_WORD_SYM, TRAINED_WORD_COUNT) = range(11)
 ERR_DIVERGED = -5
 
 u32p = C.POINTER(C.c_uint32)
@@ -73,6 +75,11 @@ def _load() -> C.CDLL:
         "mc_table_info": (C.c_int, [vp, u64p]),
         "mc_ctx_hash": (C.c_uint64, [u32p, C.c_uint32]),
         "mc_text_hash": (C.c_uint64, [u32p, C.c_uint32]),
+        "mc_train_nwords": (C.c_int, [C.c_char_p, C.c_size_t] + [C.c_uint32] * 6 + [C.POINTER(vp)]),
+        "mc_train_backwords": (C.c_int, [C.c_char_p, C.c_size_t] + [C.c_uint32] * 7 + [C.POINTER(vp)]),
+        "mc_trained_free": (None, [vp]),
+        "mc_trained_array": (C.c_int64, [vp, C.c_int, vp, C.c_size_t]),
+        "mc_trained_compile": (C.c_int, [vp] + [C.c_uint32] * 6 + [C.POINTER(vp)]),
         "mc_model_upload": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
         "mc_model_destroy": (None, [vp]),
         "mc_model_check": (C.c_int, [vp, vp, u64p]),
@@ -95,7 +102,8 @@ def _load() -> C.CDLL:
 
 lib = _load()
 EXPORTS = ["mc_abi_version", "mc_last_error", "mc_table_compile", "mc_table_free", "mc_table_array", "mc_table_info",
-           "mc_ctx_hash", "mc_text_hash", "mc_score_words_workspace_bytes", "mc_score_words", "mc_score_bpe", "mc_model_upload", "mc_model_destroy", "mc_model_check", "mc_sample", "mc_sample_injected",
+           "mc_ctx_hash", "mc_text_hash", "mc_score_words_workspace_bytes", "mc_score_words", "mc_score_bpe", "mc_train_nwords", "mc_train_backwords", "mc_trained_free",
+           "mc_trained_array", "mc_trained_compile", "mc_model_upload", "mc_model_destroy", "mc_model_check", "mc_sample", "mc_sample_injected",
            "mc_score", "mc_rank_workspace_bytes", "mc_rank_build", "mc_rank_query"]
 
 

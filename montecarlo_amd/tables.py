@@ -130,6 +130,25 @@ class FlatTable:
         self.max_word_len = int(self.info[nv.INFO_MULTICHAR] >> 8)
         self._lut: Optional[np.ndarray] = None
 
+    @classmethod
+    def adopt(cls, handle, kind: int, symbols: List[str], end_chr: str) -> "FlatTable":
+        """Wrap a table compiled elsewhere (mc_trained_compile) whose symbol ids are ``symbols``."""
+        self = cls.__new__(cls)
+        self.kind = kind
+        self._h = handle
+        self.symbols = list(symbols)
+        self.sym_id = {s: i for i, s in enumerate(symbols)}
+        self.units, self.unit_id = self.symbols, self.sym_id
+        self.end_chr, self.end_sym = end_chr, self.sym_id[end_chr]
+        self.ctx_row = {}
+        info = (C.c_uint64 * 16)()
+        nv.check(nv.lib.mc_table_info(self._h, info))
+        self.info = list(info)
+        self.multichar = bool(self.info[nv.INFO_MULTICHAR] & 1)
+        self.max_word_len = int(self.info[nv.INFO_MULTICHAR] >> 8)
+        self._lut = None
+        return self
+
     def __del__(self):
         h = getattr(self, "_h", None)
         if h and nv is not None and getattr(nv, "lib", None) is not None:   # (module may be gone at exit)

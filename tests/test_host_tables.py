@@ -209,6 +209,29 @@ def test_dense_transitions_equal_backoff_chain(train_char):
     assert len(sub._flat.array(nv.ARR_DENSE)) == 0          # sub-word alphabets keep the hash + DFS path
 
 
+def test_native_trainers_equal_python_trainers(train_char, train_tab):
+    """csrc/mc_train.cpp against the Python trainers of the same contract (which serve the
+    regular-expression splitters): identical rows, orders, probabilities and `words`."""
+    from montecarlo_amd.backwords.backwords_trainer import backwords_counter
+    from montecarlo_amd.lib4mc.ProbLib import expand_2d
+    from montecarlo_amd.nwords.nwords_trainer import nwords_counter
+    for lines, splitter, thr in ((train_char, "", 10), (train_tab, "\t", 3), (train_char + ["", "x", "\r"], "", 2)):
+        m = BackWordsMonteCarlo(synth.as_file(lines), splitter=splitter, threshold=thr)
+        assert hasattr(m, "_trained")
+        probs, words = backwords_counter(synth.as_file(lines), splitter, "\x00", "\x03", 0, 1, thr, 256)
+        assert rows_of(m.nwords) == rows_of(expand_2d(probs))
+        assert list(m.words.items()) == list(words.items())
+    for lines, splitter, n in ((train_char, "", 3), (train_tab, "\t", 2)):
+        m = NWordsMonteCarlo(synth.as_file(lines), n=n, splitter=splitter)
+        assert hasattr(m, "_trained")
+        probs, words = nwords_counter(synth.as_file(lines), n, splitter, "\x03", 0, 1)
+        assert rows_of(m.nwords) == rows_of(expand_2d(probs))
+        assert list(m.words.items()) == list(words.items())
+    # a regular-expression splitter is served by the Python trainer
+    m = NWordsMonteCarlo(synth.as_file(train_tab), n=2, splitter="\t+")
+    assert not hasattr(m, "_trained") and len(m.nwords) > 0
+
+
 def test_compile_rejects_bad_tables():
     from montecarlo_amd.lib4mc.ProbLib import expand_2d
     from montecarlo_amd.tables import FlatTable

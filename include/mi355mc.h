@@ -257,6 +257,19 @@ int mc_sample(mc_model *m, uint64_t first_id, uint64_t count, uint64_t seed, uin
               double *out_ml2p, uint32_t *out_len, uint32_t *out_draws, uint32_t *out_syms,
               uint32_t sym_stride, void *stream);
 
+/* ---- sampled strings, deduplicated on the GPU: what MonteCarlo.sample builds in `sampled_pwds`
+ * (lib4mc/MonteCarloParent.py:40-45: string -> [ml2p of its first occurrence, occurrences], in
+ * first-sampled order) and backwords_secondary_main.py:45-51 consumes.  Input: the symbol rows
+ * mc_sample wrote (out_syms, out_len, sym_stride).  Every string is inserted into an open-addressed
+ * table of `cap` slots (a power of two >= 2 * count; the three table arrays are outputs the call
+ * initialises): tab_key = 64-bit hash of the row (~0 = empty slot), tab_first = smallest sample
+ * index holding the string, tab_cnt = occurrences.  Rows longer than sym_stride are skipped
+ * (tab_cnt does not count them: the caller replays those sample ids).  A second kernel compares
+ * every row with its slot's first row; *mismatch (device) counts the rows that differ, i.e. hash
+ * collisions -- the caller must treat a non-zero count as an error. */
+int mc_sample_dedup(const uint32_t *syms, const uint32_t *len, uint32_t sym_stride, uint64_t count, uint64_t cap,
+                    uint64_t *tab_key, uint64_t *tab_first, uint32_t *tab_cnt, uint32_t *mismatch, void *stream);
+
 /* Same walk with caller-injected uniforms (parity mode: "same injected uniform stream ->
  * bit-identical strings").  Sample i consumes uniforms[i*draws_per_sample + k], k = 0,1,...;
  * a sample that needs more than draws_per_sample is reported failed (ml2p = NaN). */

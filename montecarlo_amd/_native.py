@@ -85,6 +85,7 @@ def _load() -> C.CDLL:
         "mc_model_check": (C.c_int, [vp, vp, u64p]),
         "mc_sample": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, vp, vp, vp, vp, C.c_uint32, vp]),
         "mc_sample_injected": (C.c_int, [vp, C.c_uint64, vp, C.c_uint32, vp, vp, vp, vp, C.c_uint32, vp]),
+        "mc_sample_dedup": (C.c_int, [vp, vp, C.c_uint32, C.c_uint64, C.c_uint64, vp, vp, vp, vp, vp]),
         "mc_score": (C.c_int, [vp, vp, vp, C.c_uint64, vp, vp]),
         "mc_score_words_workspace_bytes": (C.c_size_t, [vp, C.c_uint64, C.c_uint32]),
         "mc_score_words": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint64, vp, vp, C.c_uint32, vp,
@@ -103,7 +104,7 @@ def _load() -> C.CDLL:
 lib = _load()
 EXPORTS = ["mc_abi_version", "mc_last_error", "mc_table_compile", "mc_table_free", "mc_table_array", "mc_table_info",
            "mc_ctx_hash", "mc_text_hash", "mc_score_words_workspace_bytes", "mc_score_words", "mc_score_bpe", "mc_train_nwords", "mc_train_backwords", "mc_trained_free",
-           "mc_trained_array", "mc_trained_compile", "mc_model_upload", "mc_model_destroy", "mc_model_check", "mc_sample", "mc_sample_injected",
+           "mc_trained_array", "mc_trained_compile", "mc_model_upload", "mc_model_destroy", "mc_model_check", "mc_sample", "mc_sample_injected", "mc_sample_dedup",
            "mc_score", "mc_rank_workspace_bytes", "mc_rank_build", "mc_rank_query"]
 
 

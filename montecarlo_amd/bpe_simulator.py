@@ -90,8 +90,8 @@ class BpePcfgSim(MonteCarlo):
         self._dev.check()
         return float(res["ml2p"].cpu()[0]), self._strings_of(res, seed, first)[0]
 
-    def _strings_of(self, res, seed: int, first: int) -> List[str]:
-        return self._flat.decode_entries(res["syms"].cpu().numpy(), res["len"].cpu().numpy())
+    def _decode_rows(self, syms, lens) -> List[str]:
+        return self._flat.decode_entries(syms, lens)
 
     def _sample_stride(self) -> int:
         return self._flat.max_segments

@@ -780,6 +780,60 @@ __global__ void __launch_bounds__(256) k_score_bpe(DevModel m, const uint32_t *_
     }
 }
 
+// ---- GPU-side `sampled_pwds` (MonteCarloParent.py:40-45): string -> (first sample, occurrences) ----
+__device__ __forceinline__ unsigned long long row_hash(const uint32_t *row, uint32_t n) {
+    unsigned long long h = 0xCBF29CE484222325ull ^ n;
+    for (uint32_t j = 0; j < n; ++j) h = (h ^ row[j]) * 0x100000001B3ull;
+    h = mix64(h);
+    return h == ~0ull ? ~0ull - 1 : h;
+}
+
+__global__ void __launch_bounds__(256) k_dedup_insert(const uint32_t *__restrict__ syms, const uint32_t *__restrict__ len,
+                                                      uint32_t stride, unsigned long long count,
+                                                      unsigned long long mask, unsigned long long *tab_key,
+                                                      unsigned long long *tab_first, uint32_t *tab_cnt) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t n = len[i];
+        if (n > stride) continue;  // truncated row: the caller replays this sample
+        const unsigned long long h = row_hash(syms + i * stride, n);
+        for (unsigned long long q = h & mask;; q = (q + 1) & mask) {
+            const unsigned long long old = atomicCAS(&tab_key[q], ~0ull, h);
+            if (old == ~0ull || old == h) {
+                atomicMin(&tab_first[q], i);
+                atomicAdd(&tab_cnt[q], 1u);
+                break;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_dedup_verify(const uint32_t *__restrict__ syms, const uint32_t *__restrict__ len,
+                                                      uint32_t stride, unsigned long long count,
+                                                      unsigned long long mask,
+                                                      const unsigned long long *__restrict__ tab_key,
+                                                      const unsigned long long *__restrict__ tab_first,
+                                                      uint32_t *mismatch) {
+    unsigned int bad = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t n = len[i];
+        if (n > stride) continue;
+        const uint32_t *row = syms + i * stride;
+        const unsigned long long h = row_hash(row, n);
+        unsigned long long q = h & mask;
+        while (tab_key[q] != h) q = (q + 1) & mask;  // inserted by k_dedup_insert
+        const unsigned long long rep = tab_first[q];
+        if (rep == i) continue;
+        const uint32_t *other = syms + rep * stride;
+        bool same = len[rep] == n;
+        for (uint32_t j = 0; j < n && same; ++j) same = row[j] == other[j];
+        if (!same) ++bad;
+    }
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_down(bad, o);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(mismatch, bad);
+}
+
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 }  // namespace
@@ -1075,6 +1129,32 @@ extern "C" int mc_score_bpe(mc_model *m, const uint32_t *cps, const uint8_t *cls
     dim3 g((unsigned)(want < cap ? want : cap)), b(256);
     hipLaunchKernelGGL(k_score_bpe, g, b, 0, (hipStream_t)stream, m->dev, cps, cls, (const unsigned long long *)off,
                        (unsigned long long)count, out_ml2p);
+    HIP_TRY(hipGetLastError());
+    return MC_OK;
+}
+
+extern "C" int mc_sample_dedup(const uint32_t *syms, const uint32_t *len, uint32_t sym_stride, uint64_t count,
+                               uint64_t cap, uint64_t *tab_key, uint64_t *tab_first, uint32_t *tab_cnt,
+                               uint32_t *mismatch, void *stream) {
+    if (!tab_key || !tab_first || !tab_cnt || !mismatch || (count && (!syms || !len)) || sym_stride == 0 ||
+        cap < 2 * count || cap == 0 || (cap & (cap - 1))) {
+        mc_set_error("mc_sample_dedup: bad argument (cap must be a power of two >= 2 * count)");
+        return MC_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(tab_key, 0xFF, cap * sizeof(uint64_t), s));
+    HIP_TRY(hipMemsetAsync(tab_first, 0xFF, cap * sizeof(uint64_t), s));
+    HIP_TRY(hipMemsetAsync(tab_cnt, 0, cap * sizeof(uint32_t), s));
+    HIP_TRY(hipMemsetAsync(mismatch, 0, sizeof(uint32_t), s));
+    if (count == 0) return MC_OK;
+    unsigned long long want = (count + 255) / 256;
+    dim3 g((unsigned)(want < 8192 ? want : 8192)), b(256);
+    hipLaunchKernelGGL(k_dedup_insert, g, b, 0, s, syms, len, sym_stride, (unsigned long long)count,
+                       (unsigned long long)(cap - 1), (unsigned long long *)tab_key, (unsigned long long *)tab_first,
+                       tab_cnt);
+    hipLaunchKernelGGL(k_dedup_verify, g, b, 0, s, syms, len, sym_stride, (unsigned long long)count,
+                       (unsigned long long)(cap - 1), (const unsigned long long *)tab_key,
+                       (const unsigned long long *)tab_first, mismatch);
     HIP_TRY(hipGetLastError());
     return MC_OK;
 }

@@ -69,6 +69,26 @@ class DeviceModel:
                                       _vp(ln), _vp(dr), _vp(sy), sym_stride, self._stream()))
         return {"ml2p": ml2p, "len": ln, "draws": dr, "syms": sy}
 
+    def dedup(self, syms: torch.Tensor, lens: torch.Tensor, count: int):
+        """GPU-side `sampled_pwds`: -> (first sample index of every distinct row, ascending; its
+        occurrences; indices of rows longer than the stride, which the caller replays)."""
+        stride = syms.shape[1]
+        cap = 1 << max(4, (2 * count - 1).bit_length())
+        with torch.cuda.device(self.tdev):
+            key = torch.empty(cap, dtype=torch.int64, device=self.tdev)
+            first = torch.empty(cap, dtype=torch.int64, device=self.tdev)
+            cnt = torch.empty(cap, dtype=torch.int32, device=self.tdev)
+            bad = torch.empty(1, dtype=torch.int32, device=self.tdev)
+            nv.check(nv.lib.mc_sample_dedup(_vp(syms), _vp(lens), stride, count, cap, _vp(key), _vp(first), _vp(cnt),
+                                            _vp(bad), self._stream()))
+            if int(bad.item()):
+                raise RuntimeError(f"{int(bad.item())} sampled strings collide in the 64-bit row hash")
+            slots = torch.nonzero(cnt).flatten()
+            f, c = first[slots], cnt[slots].to(torch.int64)
+            order = torch.argsort(f)
+            long_ids = torch.nonzero(lens[:count] > stride).flatten()
+        return f[order], c[order], long_ids
+
     def sample_injected(self, uniforms, want_draws: bool = True, sym_stride: int = 0):
         """Parity mode: ``uniforms[i, k]`` is the k-th uniform of sample i."""
         u = torch.as_tensor(np.ascontiguousarray(uniforms, dtype=np.float64)) if not torch.is_tensor(uniforms) \

@@ -102,15 +102,13 @@ class MonteCarlo(metaclass=abc.ABCMeta):
         res = self._dev.sample(size, seed, first_id=first, max_draws=self.max_draws, sym_stride=stride)
         self._dev.check()
         if want:
-            strings = self._strings_of(res, seed, first)
-            ml2p = res["ml2p"].cpu().numpy().tolist()
             seen: Dict[str, List] = {}
-            for x, pwd in zip(ml2p, strings):
+            for pwd, x, c in self._distinct_strings(res, size, seed, first):
                 hit = seen.get(pwd)
                 if hit is None:
-                    seen[pwd] = [x, 1]
+                    seen[pwd] = [x, c]
                 else:
-                    hit[1] += 1
+                    hit[1] += c
             if clearIfNotNone:
                 sampled_pwds.clear()
             sampled_pwds.update(seen)
@@ -120,16 +118,37 @@ class MonteCarlo(metaclass=abc.ABCMeta):
         """Symbols kept per sample when strings are wanted (longer ones are replayed one by one)."""
         return 32
 
+    def _decode_rows(self, syms: np.ndarray, lens: np.ndarray) -> List[str]:
+        drop = getattr(self, "start_chr", "") or ""
+        return self._flat.decode(syms, lens, drop=drop)
+
+    def _distinct_strings(self, res, size: int, seed: int, first: int):
+        """(string, ml2p of its first occurrence, occurrences) in first-sampled order: the rows are
+        deduplicated on the GPU (mc_sample_dedup), only one row per distinct string comes to the host."""
+        stride = res["syms"].shape[1]
+        idx, cnt, long_ids = self._dev.dedup(res["syms"], res["len"], size)
+        rows = res["syms"][idx].cpu().numpy()
+        lens = res["len"][idx].cpu().numpy()
+        ml2p = res["ml2p"][idx].cpu().numpy().tolist()
+        recs = list(zip(idx.cpu().numpy().tolist(), self._decode_rows(rows, lens), ml2p, cnt.cpu().numpy().tolist()))
+        for i in long_ids.cpu().numpy().tolist():       # rare long strings: replay that sample id alone
+            n = int(res["len"][i])
+            one = self._dev.sample(1, seed, first_id=first + i, max_draws=self.max_draws, sym_stride=n)
+            pwd = self._decode_rows(one["syms"].cpu().numpy(), one["len"].cpu().numpy())[0]
+            recs.append((i, pwd, float(one["ml2p"].cpu()[0]), 1))
+        if len(long_ids):
+            recs.sort(key=lambda r: r[0])
+        return [(p, x, c) for _, p, x, c in recs]
+
     def _strings_of(self, res, seed: int, first: int) -> List[str]:
         lens = res["len"].cpu().numpy()
         syms = res["syms"].cpu().numpy()
         stride = syms.shape[1]
-        drop = getattr(self, "start_chr", "") or ""
-        out = self._flat.decode(syms, np.minimum(lens, stride), drop=drop)
+        out = self._decode_rows(syms, np.minimum(lens, stride))
         for i in np.nonzero(lens > stride)[0]:       # rare long strings: replay that sample id alone
             one = self._dev.sample(1, seed, first_id=first + int(i), max_draws=self.max_draws,
                                    sym_stride=int(lens[i]))
-            out[i] = self._flat.decode(one["syms"].cpu().numpy(), one["len"].cpu().numpy(), drop=drop)[0]
+            out[i] = self._decode_rows(one["syms"].cpu().numpy(), one["len"].cpu().numpy())[0]
         return out
 
     def _sample_by_loop(self, size, sampled_pwds, clearIfNotNone):

@@ -284,6 +284,31 @@ def test_launch_geometry_does_not_change_results(big_model):
     assert torch.equal(a.view(torch.int64), b.view(torch.int64))
 
 
+def test_sampled_pwds_dedup_on_gpu(big_model):
+    """MonteCarlo.sample(size, sampled_pwds): the dict built from the GPU-side dedup (one row per
+    distinct string reaches the host) equals the one built by decoding every sample, in content and
+    in first-sampled order -- also when most strings are longer than the kept stride (replays)."""
+    m, cm = big_model
+    n, seed = 60000, 31337
+    want = cm.sample(n, seed, stride=40)
+    strings = cm.strings({"syms": want["syms"], "len": want["len"]})
+    ref = {}
+    for x, pwd in zip(want["ml2p"].tolist(), strings):
+        ref.setdefault(pwd, [x, 0])[1] += 1
+    for stride in (32, 7):
+        m._sample_stride = lambda stride=stride: stride
+        m.seed(seed)
+        got = {"stale": [0.0, 1]}
+        keys = m.sample(n, got)
+        assert list(got.items()) == list(ref.items())
+        assert np.array_equal(np.array(keys.tolist()).view(np.uint64), want["ml2p"].view(np.uint64))
+    del m._sample_stride
+    m.seed(seed)
+    more = dict(got)
+    m.sample(1000, more, clearIfNotNone=False)
+    assert len(more) >= len(got) and list(more)[:len(got)] == list(got)
+
+
 def test_scoring_matches_c_oracle(big_model):
     m, cm = big_model
     test = list(dict.fromkeys(synth.zipf_corpus(30000, oov_frac=0.02, stream=1))) + ["", "a" * 300]

@@ -104,6 +104,12 @@ class BpePcfgSim(MonteCarlo):
     def score_batch(self, pwds: List[str]):
         if not pwds:
             return [], []
+        cps, cls, off = self.encode(pwds)
+        ml2p = self._dev.score_bpe(cps, cls, off).cpu().numpy().tolist()
+        return ml2p, [[p] for p in pwds]
+
+    def encode(self, pwds: List[str]):
+        """Passwords -> (code points, luds character classes, offsets) for mc_score_bpe."""
         cps, off, _ = self._flat.encode_text(pwds)
         lut = self._cls_lut
         uniq = np.unique(cps)
@@ -112,5 +118,4 @@ class BpePcfgSim(MonteCarlo):
                 lut[c] = char_class(chr(c))
         table = np.array([lut[c] for c in uniq.tolist()], dtype=np.uint8)
         cls = table[np.searchsorted(uniq, cps)] if len(cps) else np.zeros(0, dtype=np.uint8)
-        ml2p = self._dev.score_bpe(cps, cls, off).cpu().numpy().tolist()
-        return ml2p, [[p] for p in pwds]
+        return cps, cls, off

@@ -228,6 +228,21 @@ enum {
     MC_TRAINED_WORD_COUNT = 10   /* uint64[]: ... and their occurrence counts */
 };
 int64_t mc_trained_array(const mc_trained *t, int what, void *dst, size_t cap);
+
+/* Secondary (incremental) training, backwords/backwords_secondary_trainer.py: the raw counts persist
+ * between rounds.  mc_counts_merge = backwords_counter (:23-99) on one round's training text (a new
+ * context is admitted only with a transition at/above the threshold); mc_counts_train = freq2prob
+ * (:102-121).  mc_counts_array copies the counts out (`what` as mc_trained_array; the row of the empty
+ * context comes first, then the rows in the insertion order of nwords_dict; MC_COUNTS_ENT_COUNT =
+ * uint64[n_ent] replaces the probability arrays). */
+typedef struct mc_counts mc_counts;
+#define MC_COUNTS_ENT_COUNT 16
+int mc_counts_new(mc_counts **out);
+void mc_counts_free(mc_counts *k);
+int mc_counts_merge(mc_counts *k, const char *utf8, size_t bytes, uint32_t splitter_cp, uint32_t start4word,
+                    uint32_t skip4word, uint32_t max_gram, uint32_t threshold, uint32_t start_cp, uint32_t end_cp);
+int mc_counts_train(const mc_counts *k, uint32_t threshold, mc_trained **out);
+int64_t mc_counts_array(const mc_counts *k, int what, void *dst, size_t cap);
 /* mc_table_compile on the trained rows (kind MC_KIND_NGRAM with order = n-1, or MC_KIND_BACKOFF). */
 int mc_trained_compile(const mc_trained *t, uint32_t kind, uint32_t order, uint32_t min_len, uint32_t max_len,
                        uint32_t flags, uint32_t guide_factor, mc_table **out);

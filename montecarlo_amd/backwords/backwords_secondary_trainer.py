@@ -16,6 +16,23 @@ def backwords_counter(nwords_list, splitter: str, start_chr: str, end_chr: str,
                       start4words: int, step4words: int, max_gram: int, threshold: int,
                       nwords_dict: Dict[Tuple, Dict[str, int]] = None,
                       words: Dict[str, int] = None):
+    from ..trained import NativeCounts, one_code_point, splitter_code_point
+    sig = (splitter_code_point(splitter), one_code_point(start_chr), one_code_point(end_chr))
+    if None not in sig and (nwords_dict is None or (isinstance(nwords_dict, NativeCounts)
+                                                    and nwords_dict.signature in (None, sig))):
+        # native path (csrc/mc_train.cpp): the counts live in C++ and are merged there
+        if isinstance(nwords_list, list):
+            if len(nwords_list) == 0:
+                print("No passwords for training, early return!", file=sys.stderr)
+                return ({} if nwords_dict is None else nwords_dict), ({} if words is None else words)
+            text = "".join(ln if ln.endswith("\n") else ln + "\n" for ln in nwords_list)
+        else:
+            text = read_lines_keep_open(nwords_list).read()
+        counts = NativeCounts() if nwords_dict is None else nwords_dict
+        counts.merge(text, sig[0], start4words, step4words, max_gram, threshold, sig[1], sig[2])
+        return counts, counts.words()
+    if isinstance(nwords_dict, NativeCounts):
+        nwords_dict = {ctx: dict(row) for ctx, row in nwords_dict.items()}
     if nwords_dict is None:
         nwords_dict, words = {}, {}
     if isinstance(nwords_list, list) and len(nwords_list) == 0:

@@ -97,6 +97,17 @@ struct RowTable {
         pos_key.swap(k);
         pos_val.swap(v);
     }
+    // MC_NONE when the context has no row
+    uint32_t find(const uint32_t *ctx, uint32_t n) const {
+        if (ctx_slot.empty()) return MC_NONE;
+        const size_t mask = ctx_slot.size() - 1;
+        for (size_t i = hash_ctx(ctx, n) & mask; ctx_slot[i]; i = (i + 1) & mask) {
+            const Seq &have = rows[ctx_slot[i] - 1].ctx;
+            if (have.size() == n && (n == 0 || std::memcmp(have.data(), ctx, n * sizeof(uint32_t)) == 0))
+                return ctx_slot[i] - 1;
+        }
+        return MC_NONE;
+    }
     uint32_t row_of(const uint32_t *ctx, uint32_t n) {
         if ((rows.size() + 1) * 2 > ctx_slot.size()) grow_ctx();
         const size_t mask = ctx_slot.size() - 1;
@@ -136,6 +147,7 @@ struct Corpus {
     std::vector<uint64_t> mult;
     std::vector<uint32_t> word_sym;  // `words`: symbol -> occurrences, first-seen order
     std::vector<uint64_t> word_cnt;
+    std::unordered_map<uint32_t, uint32_t> word_pos;
     uint32_t start_sym, end_sym;
 };
 
@@ -172,8 +184,11 @@ int read_corpus(const char *utf8, size_t bytes, uint32_t splitter, uint32_t firs
     }
     c.start_sym = c.syms.get(Seq{start_cp});
     c.end_sym = c.syms.get(Seq{end_cp});
+    // (symbols and `words` persist over calls on one Corpus; the unique lines are per call)
+    c.uniq.clear();
+    c.mult.clear();
     std::unordered_map<Seq, uint32_t, SeqHash> seen;
-    std::unordered_map<uint32_t, uint32_t> word_pos;
+    std::unordered_map<uint32_t, uint32_t> &word_pos = c.word_pos;
     Seq line, secs, col;
     size_t at = 0;
     while (at < bytes) {
@@ -434,6 +449,204 @@ extern "C" int mc_train_backwords(const char *utf8, size_t bytes, uint32_t split
     }
     *out = finish(c, rows, 1);
     return MC_OK;
+}
+
+// ---- secondary (incremental) training: backwords/backwords_secondary_trainer.py -----------------------
+// The raw counts persist between rounds; a round merges its training lines into them
+// (backwords_counter, :23-99) and probabilities are derived afterwards (freq2prob, :102-121).
+struct mc_counts {
+    Corpus c;        // symbols and `words` over every round
+    RowTable table;  // the rows of order >= 1, in the insertion order of nwords_dict
+    bool any_line = false;
+};
+
+extern "C" int mc_counts_new(mc_counts **out) {
+    if (!out) return MC_ERR_ARG;
+    *out = new mc_counts();
+    return MC_OK;
+}
+
+extern "C" void mc_counts_free(mc_counts *k) { delete k; }
+
+extern "C" int mc_counts_merge(mc_counts *k, const char *utf8, size_t bytes, uint32_t splitter_cp, uint32_t start4word,
+                               uint32_t skip4word, uint32_t max_gram, uint32_t threshold, uint32_t start_cp,
+                               uint32_t end_cp) {
+    if (!k || (bytes && !utf8)) {
+        mc_set_error("mc_counts_merge: bad argument");
+        return MC_ERR_ARG;
+    }
+    if (bytes == 0) return MC_OK;  // "No passwords for training, early return!" (:35-37)
+    Corpus &c = k->c;
+    int rc = read_corpus(utf8, bytes, splitter_cp, start4word, skip4word, 1, start_cp, end_cp, c);
+    if (rc != MC_OK) return rc;
+    if (c.uniq.empty()) return MC_OK;
+    k->any_line = true;
+    // this round's lines grouped by length, groups in first-seen order (:56, :63)
+    std::vector<uint32_t> lengths;
+    std::unordered_map<uint32_t, uint32_t> group_of;
+    std::vector<std::vector<uint32_t>> groups;
+    uint32_t longest = 2;
+    for (uint32_t i = 0; i < c.uniq.size(); ++i) {
+        const uint32_t ln = (uint32_t)c.uniq[i].size();
+        longest = std::max(longest, ln);
+        auto it = group_of.find(ln);
+        if (it == group_of.end()) {
+            group_of.emplace(ln, (uint32_t)groups.size());
+            lengths.push_back(ln);
+            groups.emplace_back();
+            groups.back().push_back(i);
+        } else {
+            groups[it->second].push_back(i);
+        }
+    }
+    std::vector<uint32_t> lines;
+    for (uint32_t n = 2; n <= std::min(max_gram, longest); ++n) {
+        lines.clear();
+        for (size_t g = 0; g < groups.size(); ++g)
+            if (lengths[g] >= n) lines.insert(lines.end(), groups[g].begin(), groups[g].end());
+        RowTable fresh;
+        count_transitions(c, lines, n - 1, fresh);
+        if (fresh.rows.empty()) break;
+        for (const Row &r : fresh.rows) {
+            uint32_t have = k->table.find(r.ctx.data(), (uint32_t)r.ctx.size());
+            if (have == MC_NONE) {
+                // a context unseen so far is admitted only with a transition at/above the threshold (:89-92)
+                bool admit = false;
+                for (uint64_t v : r.cnt) admit = admit || v >= threshold;
+                if (!admit) continue;
+                have = k->table.row_of(r.ctx.data(), (uint32_t)r.ctx.size());
+            }
+            for (size_t j = 0; j < r.sym.size(); ++j) k->table.add(have, r.sym[j], r.cnt[j]);
+        }
+    }
+    return MC_OK;
+}
+
+namespace {
+// the zero-gram row of nwords_dict: every symbol but the start symbol, counted per occurrence (:49-54)
+Row zero_row(const Corpus &c) {
+    Row z;
+    for (size_t i = 0; i < c.word_sym.size(); ++i)
+        if (c.word_sym[i] != c.start_sym) {
+            z.sym.push_back(c.word_sym[i]);
+            z.cnt.push_back(c.word_cnt[i]);
+        }
+    return z;
+}
+}  // namespace
+
+// freq2prob (:102-121) -> rows ready for mc_trained_compile
+extern "C" int mc_counts_train(const mc_counts *k, uint32_t threshold, mc_trained **out) {
+    if (!k || !out) {
+        mc_set_error("mc_counts_train: bad argument");
+        return MC_ERR_ARG;
+    }
+    *out = nullptr;
+    if (!k->any_line) {
+        mc_set_error("mc_counts_train: no training line has been merged yet");
+        return MC_ERR_ARG;
+    }
+    const Row zero = zero_row(k->c);
+    std::vector<const Row *> order;
+    order.push_back(&zero);
+    for (const Row &r : k->table.rows) order.push_back(&r);
+    std::stable_sort(order.begin(), order.end(),
+                     [](const Row *a, const Row *b) { return a->ctx.size() < b->ctx.size(); });
+    std::vector<ProbRow> rows;
+    std::unordered_map<Seq, uint32_t, SeqHash> row_index;
+    for (const Row *r : order) {
+        uint64_t total = 0;
+        for (uint64_t v : r->cnt) total += v;
+        ProbRow pr;
+        pr.ctx = r->ctx;
+        std::unordered_map<uint32_t, uint32_t> at;
+        double kept_sum = 0.0;
+        bool first = true;
+        for (size_t j = 0; j < r->sym.size(); ++j)
+            if (r->cnt[j] >= threshold) {
+                const double p = (double)r->cnt[j] / (double)total;
+                at.emplace(r->sym[j], (uint32_t)pr.sym.size());
+                pr.sym.push_back(r->sym[j]);
+                pr.p.push_back(p);
+                kept_sum = first ? p : kept_sum + p;
+                first = false;
+            }
+        if (pr.sym.empty()) continue;  // every transition is below the threshold (:107-110)
+        if (pr.sym.size() < r->sym.size() && !r->ctx.empty()) {
+            const double missing = 1.0 - kept_sum;
+            auto pit = row_index.find(Seq(r->ctx.begin() + 1, r->ctx.end()));
+            if (pit == row_index.end()) {
+                mc_set_error("freq2prob: a row's parent context has no probabilities (the reference raises KeyError, "
+                             "backwords_secondary_trainer.py:117)");
+                return MC_ERR_TABLE;
+            }
+            const ProbRow &par = rows[pit->second];
+            for (size_t j = 0; j < par.sym.size(); ++j) {
+                const double add = par.p[j] * missing;
+                auto it = at.find(par.sym[j]);
+                if (it == at.end()) {
+                    at.emplace(par.sym[j], (uint32_t)pr.sym.size());
+                    pr.sym.push_back(par.sym[j]);
+                    pr.p.push_back(0.0 + add);
+                } else {
+                    pr.p[it->second] = pr.p[it->second] + add;
+                }
+            }
+        }
+        row_index.emplace(pr.ctx, (uint32_t)rows.size());
+        rows.push_back(std::move(pr));
+    }
+    *out = finish(k->c, rows, 1);
+    return MC_OK;
+}
+
+// the counts as flat arrays (for the Python view that gets pickled): zero-gram row first, then the rows
+// in insertion order; `what` as for mc_trained_array, MC_TRAINED_ENT_PROB/CUM/ML2P replaced by
+// MC_COUNTS_ENT_COUNT
+extern "C" int64_t mc_counts_array(const mc_counts *k, int what, void *dst, size_t cap) {
+    if (!k) return MC_ERR_ARG;
+    std::vector<uint32_t> u32;
+    std::vector<uint64_t> u64;
+    const Row zero = zero_row(k->c);
+    std::vector<const Row *> rows;
+    if (k->any_line) rows.push_back(&zero);
+    for (const Row &r : k->table.rows) rows.push_back(&r);
+    bool wide = false;
+    switch (what) {
+        case MC_TRAINED_CTX_OFF:
+            u32.push_back(0);
+            for (const Row *r : rows) u32.push_back(u32.back() + (uint32_t)r->ctx.size());
+            break;
+        case MC_TRAINED_CTX_UNITS:
+            for (const Row *r : rows) u32.insert(u32.end(), r->ctx.begin(), r->ctx.end());
+            break;
+        case MC_TRAINED_ROW_OFF:
+            wide = true;
+            u64.push_back(0);
+            for (const Row *r : rows) u64.push_back(u64.back() + r->sym.size());
+            break;
+        case MC_TRAINED_ENT_SYM:
+            for (const Row *r : rows) u32.insert(u32.end(), r->sym.begin(), r->sym.end());
+            break;
+        case MC_COUNTS_ENT_COUNT:
+            wide = true;
+            for (const Row *r : rows) u64.insert(u64.end(), r->cnt.begin(), r->cnt.end());
+            break;
+        case MC_TRAINED_SYM_TEXT_OFF:
+            u32.push_back(0);
+            for (const Seq &s : k->c.syms.text) u32.push_back(u32.back() + (uint32_t)s.size());
+            break;
+        case MC_TRAINED_SYM_TEXT:
+            for (const Seq &s : k->c.syms.text) u32.insert(u32.end(), s.begin(), s.end());
+            break;
+        case MC_TRAINED_WORD_SYM: u32 = k->c.word_sym; break;
+        case MC_TRAINED_WORD_COUNT: wide = true; u64 = k->c.word_cnt; break;
+        default: mc_set_error("mc_counts_array: unknown array %d", what); return MC_ERR_ARG;
+    }
+    const void *src = wide ? (const void *)u64.data() : (const void *)u32.data();
+    const size_t bytes = wide ? u64.size() * 8 : u32.size() * 4;
+    if (dst && cap) std::memcpy(dst, src, std::min(cap, bytes));
+    return (int64_t)bytes;
 }
 
 extern "C" void mc_trained_free(mc_trained *t) { delete t; }

@@ -232,6 +232,30 @@ def test_native_trainers_equal_python_trainers(train_char, train_tab):
     assert not hasattr(m, "_trained") and len(m.nwords) > 0
 
 
+def test_native_secondary_counts_equal_python(train_char):
+    """mc_counts (merge + freq2prob in C++) against the Python secondary trainer: same raw counts (content
+    and dict order) after every merge, same probability tables, and the pickle is a plain dict."""
+    import pickle
+    from montecarlo_amd.backwords.backwords_secondary_trainer import freq2prob
+    from montecarlo_amd.lib4mc.ProbLib import expand_2d
+    from montecarlo_amd.trained import NativeCounts
+    rounds = [train_char[:1500], train_char[1500:1900] + ["", "zz"], [], train_char[1900:2000]]
+    nat = natw = py = pyw = None
+    py, pyw = {}, {}
+    for lines in rounds:
+        nat, natw = secondary_counter(list(lines), "", "\x03", "\x00", 0, 1, 256, 3, nwords_dict=nat, words=natw)
+        py, pyw = secondary_counter(list(lines), "", "\x03", "\x00", 0, 1, 256, 3, nwords_dict=py, words=pyw)
+        assert isinstance(nat, NativeCounts) and not isinstance(py, NativeCounts)
+        assert [(k, list(v.items())) for k, v in nat.items()] == [(k, list(v.items())) for k, v in py.items()]
+        assert list(natw.items()) == list(pyw.items())
+        cfg = {"start_chr": "\x03", "end_chr": "\x00", "threshold": 3}
+        m = BackWordsSecondaryMonteCarlo((nat, natw, cfg))
+        assert hasattr(m, "_trained")
+        assert rows_of(m.nwords) == rows_of(expand_2d(freq2prob(py, 3)))
+    back = pickle.loads(pickle.dumps((nat, natw, cfg)))
+    assert type(back[0]) is dict and back[0] == py
+
+
 def test_compile_rejects_bad_tables():
     from montecarlo_amd.lib4mc.ProbLib import expand_2d
     from montecarlo_amd.tables import FlatTable

@@ -247,6 +247,22 @@ int64_t mc_counts_array(const mc_counts *k, int what, void *dst, size_t cap);
 int mc_trained_compile(const mc_trained *t, uint32_t kind, uint32_t order, uint32_t min_len, uint32_t max_len,
                        uint32_t flags, uint32_t guide_factor, mc_table **out);
 
+/* ---- test-file ingest (host) ---------------------------------------------------------------*/
+/* Replaces the counting loop of MonteCarlo.parse_file (lib4mc/MonteCarloParent.py:56-60): the lines of
+ * `utf8` ('\n' line ends; '\r' and '\n' stripped from both ends, as line.strip("\r\n")), deduplicated in
+ * first-seen order -- the insertion order of the reference's pwd_counter dict.  mc_lines_array copies
+ * up to `cap` bytes into dst and returns the full size in bytes (as mc_trained_array does). */
+typedef struct mc_lines mc_lines;
+enum {
+    MC_LINES_COUNT = 0, /* uint64[n_unique]    occurrences of each unique line                         */
+    MC_LINES_OFF = 1,   /* uint64[n_unique+1]  offsets of the unique lines in MC_LINES_CPS             */
+    MC_LINES_CPS = 2,   /* uint32[]            their code points, concatenated (mc_score_words' input) */
+    MC_LINES_INFO = 3   /* uint64[4]           unique lines, lines, longest unique line, code points   */
+};
+int mc_lines_ingest(const char *utf8, size_t bytes, mc_lines **out);
+void mc_lines_free(mc_lines *l);
+int64_t mc_lines_array(const mc_lines *l, int what, void *dst, size_t cap);
+
 /* ---- device residency ---------------------------------------------------------------------*/
 /* Uploads the compiled table to GPU `device` (one hipMalloc arena). */
 int mc_model_upload(const mc_table *t, int device, mc_model **out);

@@ -34,15 +34,10 @@ class TableBacked:
         return ml2p[0], parts[0]
 
     def score_batch(self, pwds: List[str]):
-        flat = self._flat
-        end = self.end_chr
-        if not flat.multichar:
-            # single-character alphabets have exactly one parse: the lookup-chain kernel
-            syms, off = flat.encode_chars(pwds)
-            ml2p = self._dev.score_ids(syms, off).cpu().numpy().tolist()
-            parts = [[c for c in p if c != end] if m < UNPARSEABLE else ([p] if p != end else [])
-                     for p, m in zip(pwds, ml2p)]
-            return ml2p, parts
+        pwds = list(pwds)
+        if not self._flat.multichar:
+            syms, off = self._flat.encode_chars(pwds)
+            return self._score_chars(pwds, syms, off, True)
         return self.score_batch_dfs(pwds)
 
     def score_batch_dfs(self, pwds: List[str]):
@@ -50,10 +45,33 @@ class TableBacked:
         if not pwds:
             return [], []
         cps, off, max_len = self._flat.encode_text(pwds)
+        return self._score_words(pwds, cps, off, max_len, True)
+
+    def _score_unique(self, lines, pwds: List[str], want_parts: bool):
+        """score_batch on lines the native ingest has already encoded (montecarlo_amd.ingest)."""
+        if not pwds:
+            return [], []
+        if not self._flat.multichar:
+            return self._score_chars(pwds, self._flat.char_lut()[lines.cps], lines.off, want_parts)
+        return self._score_words(pwds, lines.cps, lines.off, lines.longest, want_parts)
+
+    def _score_chars(self, pwds, syms, off, want_parts: bool):
+        # single-character alphabets have exactly one parse: the lookup-chain kernel
+        end = self.end_chr
+        ml2p = self._dev.score_ids(syms, off).cpu().numpy().tolist()
+        if not want_parts:
+            return ml2p, None
+        parts = [[c for c in p if c != end] if m < UNPARSEABLE else ([p] if p != end else [])
+                 for p, m in zip(pwds, ml2p)]
+        return ml2p, parts
+
+    def _score_words(self, pwds, cps, off, max_len: int, want_parts: bool):
         iter_max = getattr(self, "max_iter", 10 ** 35)          # nwords_simulator.py:88 passes 1e35
         res, split = self._dev.score_words(cps, off, max_len, iter_max)
         self._dev.check()
         ml2p = res.cpu().numpy().tolist()
+        if not want_parts:
+            return ml2p, None
         masks = split.cpu().numpy().view(np.uint64)
         end = self.end_chr
         parts = []

@@ -23,3 +23,6 @@ class NWords2MonteCarlo(TableBacked, MonteCarlo):
 
     def score_batch(self, pwds):
         raise NotImplementedError("nwords_v2 scoring has no working reference (its calc_ml2p is defective)")
+
+    def _score_unique(self, lines, pwds, want_parts):
+        return self.score_batch(pwds)

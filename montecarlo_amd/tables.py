@@ -173,18 +173,22 @@ class FlatTable:
     # ---- host-side encode/decode of strings -----------------------------------------------
     def encode_chars(self, pwds: Iterable[str]):
         """Passwords -> (symbol ids, offsets) for single-character alphabets."""
+        pwds = list(pwds)
+        lens = np.fromiter((len(p) for p in pwds), dtype=np.uint64, count=len(pwds))
+        off = np.zeros(len(pwds) + 1, dtype=np.uint64)
+        np.cumsum(lens, out=off[1:])
+        cps = np.frombuffer("".join(pwds).encode("utf-32-le", "surrogatepass"), dtype="<u4")
+        return self.char_lut()[cps], off
+
+    def char_lut(self) -> np.ndarray:
+        """code point -> symbol id (MC_NONE outside the alphabet), single-character symbols only."""
         if self._lut is None:
             lut = np.full(0x110000, nv.MC_NONE, dtype=np.uint32)
             for s, i in self.sym_id.items():
                 if len(s) == 1:
                     lut[ord(s)] = i
             self._lut = lut
-        pwds = list(pwds)
-        lens = np.fromiter((len(p) for p in pwds), dtype=np.uint64, count=len(pwds))
-        off = np.zeros(len(pwds) + 1, dtype=np.uint64)
-        np.cumsum(lens, out=off[1:])
-        cps = np.frombuffer("".join(pwds).encode("utf-32-le", "surrogatepass"), dtype="<u4")
-        return self._lut[cps], off
+        return self._lut
 
     @staticmethod
     def encode_text(pwds: Iterable[str]):

@@ -309,6 +309,21 @@ def test_sampled_pwds_dedup_on_gpu(big_model):
     assert len(more) >= len(got) and list(more)[:len(got)] == list(got)
 
 
+def test_parse_file_native_ingest_equals_line_loop(big_model):
+    """parse_file through mc_lines_ingest == the reference's line loop (lib4mc/MonteCarloParent.py:56-68;
+    a text with '\\r' line ends takes the loop), 1e5 lines with duplicates, empty and out-of-model lines."""
+    m, _ = big_model
+    lines = synth.zipf_corpus(100000, oov_frac=0.02, stream=3) + ["", "", "a" * 300, "pässwörd"]
+    fast = m.parse_file(io.StringIO("\n".join(lines) + "\n"))
+    loop = m.parse_file(io.StringIO("\r\n".join(lines) + "\r\n"))
+    assert fast == loop
+    assert sum(c for _, c, _ in fast) == len(lines)
+    assert [x for _, _, x in fast] == sorted(x for _, _, x in fast)
+    comp_fast = m.parse_file(io.StringIO("\n".join(lines[:5000])), using_component=True)
+    comp_loop = m.parse_file(io.StringIO("\r\n".join(lines[:5000])), using_component=True)
+    assert comp_fast == comp_loop
+
+
 def test_scoring_matches_c_oracle(big_model):
     m, cm = big_model
     test = list(dict.fromkeys(synth.zipf_corpus(30000, oov_frac=0.02, stream=1))) + ["", "a" * 300]

@@ -263,3 +263,27 @@ def test_compile_rejects_bad_tables():
     table = expand_2d({(): {"a": .5, "\x03": .5}, ("a", "b"): {"\x03": 1.0}})
     with pytest.raises(nv.NativeError, match="prefix-closed"):
         FlatTable(table, nv.KIND_BACKOFF, start_units=("\x00",))
+
+
+def test_native_line_ingest_equals_dict_counting():
+    """mc_lines_ingest == the counting loop of parse_file (reference lib4mc/MonteCarloParent.py:56-60):
+    unique lines in first-seen order, multiplicities, code points."""
+    from montecarlo_amd.ingest import UniqueLines
+    rng = np.random.default_rng(7)
+    pool = ["", "a", "password", "pässwörd", "密码123", "x" * 300, "\U0001F600ok", "tab\tinside", " lead", "trail ",
+            "abcdefgh", "abcdefgh1", "abcdefg", "\ud800lone"] + synth.zipf_corpus(3000, vocab=500)
+    lines = [pool[i] for i in rng.integers(0, len(pool), size=20000)]
+    for text in ("\n".join(lines) + "\n", "\n".join(lines), "", "\n", "\n\n", "one", "\rcr-lead\r\nx\r\n\r\n"):
+        want = {}
+        for ln in text.split("\n")[:-1] + ([text.split("\n")[-1]] if not text.endswith("\n") and text else []):
+            ln = ln.strip("\r\n")
+            want[ln] = want.get(ln, 0) + 1
+        got = UniqueLines(text)
+        assert got.strings() == list(want)
+        assert got.count.tolist() == list(want.values())
+        assert got.n_lines == sum(want.values())
+        assert got.longest == max((len(k) for k in want), default=0)
+        assert got.off.tolist() == np.concatenate([[0], np.cumsum([len(k) for k in want])]).astype(int).tolist()
+    with pytest.raises(nv.NativeError):
+        h = ctypes.c_void_p()
+        nv.check(nv.lib.mc_lines_ingest(b"ok\n\xff\xfe\n", 6, ctypes.byref(h)))

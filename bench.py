@@ -66,7 +66,8 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="rehearsal of the multi-rank control flow on a 1-GPU box: every rank uses cuda:0 and the "
                          "collective runs over gloo (the printed numbers mean nothing)")
-    ap.add_argument("--cpu-samples", type=int, default=300_000)
+    ap.add_argument("--cpu-samples", type=int, default=0,
+                    help="samples of the CPU baseline leg (default: the whole workload, about 10-20 s of one core)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -207,31 +208,45 @@ def main():
                                     "active_passes": active, "kernel_ms": ms["rank"]},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(model, test, args.cpu_samples)
+            out["cpu_baseline"] = cpu_baseline(model, test, args.cpu_samples or N)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
 def cpu_baseline(model, test, n_samples: int):
-    """The C restatement of the reference's algorithm (oracle/mc_oracle.c), one host thread, on a
-    bounded sample of the same workload: n_samples samples + their rank build + 1/10 as many
-    test passwords scored and ranked."""
+    """The C restatement of the reference's algorithm (oracle/mc_oracle.c), one host thread, on the
+    same workload (by default all of it: n_samples samples + their rank build + the test passwords
+    in the same proportion scored and ranked; about 10-20 s).  Only the C calls are timed: flattening
+    the model and encoding the test set are outside, as they are outside the GPU's timed region."""
+    import ctypes as C
+
     from oracle import c_oracle
     cm = c_oracle.COracleModel(model.nwords, c_oracle.KIND_BACKOFF, start_units=["\x00"])
-    t_n = max(1000, n_samples // 10)
+    t_n = min(len(test), max(1000, n_samples // 10))
+    lut = np.full(0x110000, c_oracle.NONE, dtype=np.uint32)
+    for s, i in cm.sym_id.items():
+        if len(s) == 1:
+            lut[ord(s)] = i
+    pw = test[:t_n]
+    off = np.zeros(t_n + 1, dtype=np.uint64)
+    np.cumsum(np.fromiter((len(p) for p in pw), dtype=np.uint64, count=t_n), out=off[1:])
+    ids = np.append(lut[np.frombuffer("".join(pw).encode("utf-32-le", "surrogatepass"), dtype="<u4")], np.uint32(0))
+    sc = np.empty(t_n, dtype=np.float64)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
     t0 = time.perf_counter()
     res = cm.sample(n_samples, 20250304)
     t1 = time.perf_counter()
     srt, pos = c_oracle.rank_build(res["ml2p"])
     t2 = time.perf_counter()
-    sc = cm.score(test[:t_n])
+    c_oracle.lib().orc_score(cm._h, vp(ids), vp(off), t_n, vp(sc))
     t3 = time.perf_counter()
     c_oracle.rank_query(srt, pos, np.sort(sc))
     t4 = time.perf_counter()
-    return {"value": n_samples / (t4 - t0), "unit": "sampled passwords/s (same pipeline, scaled sample)",
+    return {"value": n_samples / (t4 - t0), "unit": "sampled passwords/s (same pipeline)",
             "cores": 1, "kind": "port",
-            "sample": f"{n_samples} samples + rank build + {t_n} test pwds scored/ranked, oracle/mc_oracle.c",
+            "sample": f"{n_samples} samples + rank build + {t_n} test pwds scored/ranked, oracle/mc_oracle.c, "
+                      f"{t4 - t0:.1f} s of one core",
             "sampling_only_per_s": n_samples / (t1 - t0), "scored_per_s": t_n / (t3 - t2),
             "rank_build_s": t2 - t1, "reference_python_samples_per_s_build_container": 22988}
 

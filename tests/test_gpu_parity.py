@@ -386,6 +386,42 @@ def test_rank_pipeline_full_size(big_model):
     assert np.all(np.abs(rs.positions.cpu().numpy() - opos) <= REL * opos)
 
 
+def test_config3_shard_size():
+    """config 3's per-GPU share: 1e10 samples over 8 GPUs = 1.25e9 keys (10 GB per array) from the v2
+    6-gram model, through sample -> rank build -> query.  Size-independent properties: the sorted keys
+    are a permutation of the samples (wrap-around checksum, equal extremes) in ascending order; the
+    positions are monotone and end at the independently reduced sum of weights; a query's count and
+    position agree with torch.searchsorted on the sorted keys; chunked sampling == one launch."""
+    free, _ = torch.cuda.mem_get_info()
+    n = 1_250_000_000
+    if free < 60 * 2 ** 30:
+        pytest.skip("needs 60 GB of free HBM")
+    m = NWords2MonteCarlo(synth.as_file(synth.v2_corpus(100000)), 6)
+    n_global = 8 * n
+    keys = m._dev.sample(n, 5, first_id=3 * n)["ml2p"]
+    cnt = m._dev.check()
+    assert cnt["failed"] == 0 and cnt["draws"] > n
+    part = m._dev.sample(1000, 5, first_id=4 * n - 1000)["ml2p"]      # ids beyond 2^32: same values
+    assert torch.equal(part.view(torch.int64), keys[-1000:].view(torch.int64))
+    rk = DeviceRank(keys, n_global=n_global)
+    srt, pos = rk.keys_sorted, rk.positions
+    assert int(srt.view(torch.int64).sum()) == int(keys.view(torch.int64).sum())
+    assert float(srt[0]) == float(keys.min()) and float(srt[-1]) == float(keys.max())
+    step = 250_000_000
+    for lo in range(0, n, step):                                      # (bounded temporaries)
+        hi = min(n, lo + step + 1)
+        assert bool((srt[lo + 1:hi] >= srt[lo:hi - 1]).all())
+        assert bool((pos[lo + 1:hi] >= pos[lo:hi - 1]).all())
+    total = sum(float(torch.exp2(keys[lo:lo + step] - np.log2(n_global)).sum()) for lo in range(0, n, step))
+    assert abs(float(pos[-1]) - total) <= REL * total
+    x = torch.cat([srt[::1250][:999000], torch.tensor([0.0, 3000.0], dtype=torch.float64, device=srt.device)])
+    qp, qc = rk.query(x.contiguous())
+    want_c = torch.searchsorted(srt, x, right=True)
+    assert torch.equal(qc, want_c)
+    want_p = torch.where(want_c > 0, pos[(want_c - 1).clamp(min=0)], torch.zeros_like(x))
+    assert torch.equal(qp.view(torch.int64), want_p.view(torch.int64))
+
+
 def test_rank_edge_sizes():
     dev = torch.device("cuda")
     g = torch.Generator(device="cpu").manual_seed(3)

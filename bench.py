@@ -167,6 +167,7 @@ def main():
 
     # sanity on the last step (not timed): finite keys, sorted output
     assert bool(torch.isfinite(keys).all()) and bool((keys_sorted[1:] >= keys_sorted[:-1]).all())
+    assert bool(torch.isfinite(positions).all()) and bool((positions[1:] >= positions[:-1]).all())
 
     # radix passes that do anything on the last step's keys (mc_rank_build skips constant digits)
     kb = keys.view(torch.uint8).view(N, 8)

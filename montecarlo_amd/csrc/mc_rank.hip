@@ -35,18 +35,17 @@ namespace {
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
-constexpr int SORT_THREADS = 256;
-constexpr int SORT_ITEMS = 24;
-constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 4096 keys per tile
+constexpr int SORT_TILE_MIN = 4096;  // smallest tile any variant uses: sizes the look-back words
 // look-back word of (tile, digit): 2 flag bits + count
 constexpr unsigned long long LB_LOCAL = 1ull << 62;  // count of this tile alone
 constexpr unsigned long long LB_INCL = 2ull << 62;   // count of this tile and every earlier one
 constexpr unsigned long long LB_MASK = (1ull << 62) - 1;
 constexpr unsigned int LB_SPIN_LIMIT = 1u << 24;     // a bound, not a protocol: see k_onesweep
-constexpr int LB_WINDOW = 8;                         // predecessors read per look-back step
+constexpr int LB_WINDOW = 4;                         // predecessors read per look-back step
 constexpr int HIST_COPIES = 4, HIST_PITCH = 8 * 256 + 1;
+constexpr int HIST_PLAIN = 5;  // digits counted without looking for wave-wide agreement
 constexpr int SCAN_THREADS = 256;
-constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_ITEMS = 8;  // (k_positions pads its LDS tile for exactly 8)
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 constexpr int SCAN_MAX_BLOCKS = 2048;
 
@@ -98,8 +97,19 @@ __global__ void __launch_bounds__(256) k_hist_all(const u64 *__restrict__ keys, 
             const u64 diff = have[r] ? (k[r] ^ first) : 0;
             const u32 lanes = __popcll(mask);
             const bool leader = have[r] && __popcll(mask & ((1ull << (threadIdx.x & 63)) - 1ull)) == 0;
+            // the low bytes are mantissa bits: lanes agree on one only when they hold the same key (a
+            // run of one repeated password), which is the one case worth looking for
+            const bool one_key = __ballot(diff != 0) == 0;
 #pragma unroll
-            for (int p = 0; p < 8; ++p) {
+            for (int p = 0; p < HIST_PLAIN; ++p) {
+                if (one_key) {
+                    if (leader) atomicAdd(&h[p * 256 + digit_of(k[r], p)], lanes);
+                } else if (have[r]) {
+                    atomicAdd(&h[p * 256 + digit_of(k[r], p)], 1u);
+                }
+            }
+#pragma unroll
+            for (int p = HIST_PLAIN; p < 8; ++p) {
                 // a digit the whole wave agrees on (sign/exponent bytes; runs of one repeated password)
                 // costs one LDS add, not 64 colliding ones
                 const bool same = __ballot(((diff >> (8 * p)) & 255ull) != 0) == 0;
@@ -172,39 +182,53 @@ __global__ void __launch_bounds__(256) k_copy_if_unsorted(const Plan *__restrict
 // set and k_positions poisons the output with NaN (loud, not a hang).  Look-back words are written
 // and read with agent-scope atomics (the per-XCD L2s are not coherent with each other); nothing
 // else crosses workgroups.
-__global__ void __launch_bounds__(SORT_THREADS) k_onesweep(const Plan *__restrict__ plan, int pass, const u64 *in,
-                                                            u64 *a, u64 *b, u64 n, u32 tiles,
-                                                            const u32 *__restrict__ hist, u32 *err, u64 *lookback) {
+template <int THREADS, int ITEMS, int PREFETCH, int WAVES>
+__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
+k_onesweep(const Plan *__restrict__ plan, int pass, const u64 *in, u64 *a, u64 *b, u64 n, u32 tiles,
+           const u32 *__restrict__ hist, u32 *err, u64 *lookback) {
+    constexpr int TILE = THREADS * ITEMS, NW = THREADS / 64;
     if (plan->skip[pass]) return;
     const u64 *src = pick_src(plan->src[pass], in, a, b);
     u64 *dst = plan->dst[pass] == 1 ? a : b;
     u64 *lb = lookback + (u64)plan->slot[pass] * tiles * 256;
     u64 *lb_next = lookback + (u64)(1u - plan->slot[pass]) * tiles * 256;
-    __shared__ u64 stage[SORT_TILE];
-    __shared__ u32 wcnt[4][256];   // per-wave digit counts of the tile, then exclusive prefix over waves
+    __shared__ u64 stage[TILE];
+    __shared__ u32 wcnt[NW][256];  // per-wave digit counts of the tile, then exclusive prefix over waves
     __shared__ u64 base[256];      // global write offset of each digit for this tile
     __shared__ u32 tile_off[256];  // exclusive scan of the tile's digit counts
     __shared__ u32 wave_sum[4];
     __shared__ u32 wave_below[4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    for (u32 tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    for (int w = 0; w < 4; ++w) wcnt[w][tid] = 0;
-    __syncthreads();  // (also: every wave has left the previous tile's write-out)
-    const u64 t0 = (u64)tile * SORT_TILE;
-    const u32 tile_n = (u32)min((u64)SORT_TILE, n - t0);
-    lb_next[(u64)tile * 256 + tid] = 0;  // the next active pass starts from clean words
-
-    // each wave owns 1024 consecutive keys of the tile: order = (wave, round, lane)
-    u64 key[SORT_ITEMS];
-    u32 rank[SORT_ITEMS];
+    // each wave owns 64 * ITEMS consecutive keys of the tile: order = (wave, round, lane).  The 256
+    // digits belong to the first 256 lanes (waves 0..3).
+    u64 key[ITEMS], nkey[PREFETCH ? ITEMS : 1];
+    auto load_tile = [&](u32 tile, u64 *k) {
+        const u64 t0 = (u64)tile * TILE;
+        const u32 tile_n = tile < tiles ? (u32)min((u64)TILE, n - t0) : 0u;
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
-        const u32 j = wid * (64 * SORT_ITEMS) + r * 64 + lane;
-        key[r] = j < tile_n ? src[t0 + j] : ~0ull;
+        for (int r = 0; r < ITEMS; ++r) {
+            const u32 j = wid * (64 * ITEMS) + r * 64 + lane;
+            k[r] = j < tile_n ? src[t0 + j] : ~0ull;
+        }
+    };
+    if (PREFETCH) load_tile(blockIdx.x, nkey);
+    for (u32 tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    for (int i = tid; i < NW * 256; i += THREADS) (&wcnt[0][0])[i] = 0;
+    __syncthreads();  // (also: every wave has left the previous tile's write-out)
+    const u64 t0 = (u64)tile * TILE;
+    const u32 tile_n = (u32)min((u64)TILE, n - t0);
+    if (tid < 256) lb_next[(u64)tile * 256 + tid] = 0;  // the next active pass starts from clean words
+
+    u32 rank[ITEMS];
+    if (PREFETCH) {
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) key[r] = nkey[r];
+    } else {
+        load_tile(tile, key);
     }
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
-        const u32 j = wid * (64 * SORT_ITEMS) + r * 64 + lane;
+    for (int r = 0; r < ITEMS; ++r) {
+        const u32 j = wid * (64 * ITEMS) + r * 64 + lane;
         const bool valid = j < tile_n;
         const u32 d = digit_of(key[r], pass);
         // lanes of this wave holding the same digit (invalid lanes match nobody)
@@ -222,90 +246,104 @@ __global__ void __launch_bounds__(SORT_THREADS) k_onesweep(const Plan *__restric
         old = __shfl(old, leader < 0 ? 0 : leader);
         rank[r] = old + before;
     }
+    // the next tile's keys travel while this tile waits for its predecessors and writes out
+    if (PREFETCH == 1) load_tile(tile + gridDim.x, nkey);
     __syncthreads();
-    // digit `tid`: exclusive prefix over the 4 waves, tile total
-    const u32 c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid], c3 = wcnt[3][tid];
-    const u32 tot = c0 + c1 + c2 + c3;
-    u64 *mine = lb + (u64)tile * 256 + tid;
-    __hip_atomic_store(mine, (u64)tot | (tile == 0 ? LB_INCL : LB_LOCAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    wcnt[0][tid] = 0;
-    wcnt[1][tid] = c0;
-    wcnt[2][tid] = c0 + c1;
-    wcnt[3][tid] = c0 + c1 + c2;
-    // exclusive scans over the 256 digits: of the tile's counts and of the global histogram
-    u32 inc = tot, ginc = hist[pass * 256 + tid];
-    const u32 gown = ginc;
-    for (int o = 1; o < 64; o <<= 1) {
-        const u32 v = __shfl_up(inc, o), g = __shfl_up(ginc, o);
-        if (lane >= o) {
-            inc += v;
-            ginc += g;
+    u32 tot = 0, inc = 0, ginc = 0, gown = 0;
+    u64 *mine = lb + (u64)tile * 256 + (tid & 255);
+    if (tid < 256) {
+        // digit `tid`: exclusive prefix over the waves, tile total
+        u32 run = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const u32 c = wcnt[w][tid];
+            wcnt[w][tid] = run;
+            run += c;
+        }
+        tot = run;
+        __hip_atomic_store(mine, (u64)tot | (tile == 0 ? LB_INCL : LB_LOCAL), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        // exclusive scans over the 256 digits: of the tile's counts and of the global histogram
+        inc = tot;
+        ginc = gown = hist[pass * 256 + tid];
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 v = __shfl_up(inc, o), g = __shfl_up(ginc, o);
+            if (lane >= o) {
+                inc += v;
+                ginc += g;
+            }
+        }
+        if (lane == 63) {
+            wave_sum[wid] = inc;
+            wave_below[wid] = ginc;
         }
     }
-    if (lane == 63) {
-        wave_sum[wid] = inc;
-        wave_below[wid] = ginc;
-    }
     __syncthreads();
-    u32 woff = 0, gbelow = 0;
-    for (int w = 0; w < wid; ++w) {
-        woff += wave_sum[w];
-        gbelow += wave_below[w];
-    }
-    tile_off[tid] = woff + inc - tot;
-    // decoupled look-back: keys of digit `tid` in all earlier tiles, LB_WINDOW predecessors per
-    // round trip (the reads are uncached; measured at 1e7 keys: a tile walks ~40 tiles back, the
-    // look-back costs ~30 us of a pass's ~80; windows of 1..8 perform alike, 32 is slower).
-    u64 excl = 0;
-    if (tile > 0) {
-        u32 spins = 0;
-        long long p = (long long)tile - 1;  // nearest predecessor not yet accounted for
-        bool done = false;
-        while (!done) {
-            u64 v[LB_WINDOW];
+    if (tid < 256) {
+        u32 woff = 0, gbelow = 0;
+        for (int w = 0; w < wid; ++w) {
+            woff += wave_sum[w];
+            gbelow += wave_below[w];
+        }
+        tile_off[tid] = woff + inc - tot;
+        // decoupled look-back: keys of digit `tid` in all earlier tiles, LB_WINDOW predecessors per
+        // round trip (the reads are uncached; windows of 1..8 perform alike, 32 is slower).
+        u64 excl = 0;
+        if (tile > 0) {
+            u32 spins = 0;
+            long long p = (long long)tile - 1;  // nearest predecessor not yet accounted for
+            bool done = false;
+            while (!done) {
+                u64 v[LB_WINDOW];
 #pragma unroll
-            for (int j = 0; j < LB_WINDOW; ++j)
-                v[j] = p - j >= 0 ? __hip_atomic_load(lb + (u64)(p - j) * 256 + tid, __ATOMIC_RELAXED,
-                                                      __HIP_MEMORY_SCOPE_AGENT)
-                                  : LB_INCL;
-            int used = 0;
+                for (int j = 0; j < LB_WINDOW; ++j)
+                    v[j] = p - j >= 0 ? __hip_atomic_load(lb + (u64)(p - j) * 256 + tid, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT)
+                                      : LB_INCL;
+                int used = 0;
 #pragma unroll
-            for (int j = 0; j < LB_WINDOW; ++j) {
-                if (done || used != j) continue;
-                const u64 f = v[j] & ~LB_MASK;
-                if (f == 0) continue;  // not published yet: poll again from here
-                excl += v[j] & LB_MASK;
-                used = j + 1;
-                if (f != LB_LOCAL) done = true;
-            }
-            p -= used;
-            if (!done && used < LB_WINDOW) {
-                if (++spins > LB_SPIN_LIMIT) {
-                    atomicOr(err, 1u);
-                    done = true;
+                for (int j = 0; j < LB_WINDOW; ++j) {
+                    if (done || used != j) continue;
+                    const u64 f = v[j] & ~LB_MASK;
+                    if (f == 0) continue;  // not published yet: poll again from here
+                    excl += v[j] & LB_MASK;
+                    used = j + 1;
+                    if (f != LB_LOCAL) done = true;
                 }
-                __builtin_amdgcn_s_sleep(1);
+                p -= used;
+                if (!done && used < LB_WINDOW) {
+                    if (++spins > LB_SPIN_LIMIT) {
+                        atomicOr(err, 1u);
+                        done = true;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
             }
+            __hip_atomic_store(mine, (excl + tot) | LB_INCL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        __hip_atomic_store(mine, (excl + tot) | LB_INCL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        base[tid] = (u64)(gbelow + ginc - gown) + excl;
     }
-    base[tid] = (u64)(gbelow + ginc - gown) + excl;
+    if (PREFETCH == 2) load_tile(tile + gridDim.x, nkey);
     __syncthreads();
     // stage keys in LDS in digit order
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; ++r) {
-        const u32 j = wid * (64 * SORT_ITEMS) + r * 64 + lane;
+    for (int r = 0; r < ITEMS; ++r) {
+        const u32 j = wid * (64 * ITEMS) + r * 64 + lane;
         if (j < tile_n) {
             const u32 d = digit_of(key[r], pass);
-            stage[tile_off[d] + wcnt[wid][d] + rank[r]] = key[r];
+            const u32 at = tile_off[d] + wcnt[wid][d] + rank[r];
+            if (at < (u32)TILE) stage[at] = key[r]; else atomicOr(err, 2u);
         }
     }
     __syncthreads();
     // digit-contiguous runs out to global
-    for (u32 j = tid; j < tile_n; j += SORT_THREADS) {
+    for (u32 j = tid; j < tile_n; j += THREADS) {
         const u64 k = stage[j];
         const u32 d = digit_of(k, pass);
-        dst[base[d] + (j - tile_off[d])] = k;
+        // (counts that do not match the keys -- a caller overwriting them mid-sort -- must end as a
+        // poisoned result, not as a write outside the buffer)
+        const u64 at = base[d] + (j - tile_off[d]);
+        if (at < n) dst[at] = k; else atomicOr(err, 2u);
     }
     }  // next tile of this workgroup
 }
@@ -367,26 +405,50 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_positions(const double *__rest
                                                              double logn, const double *__restrict__ partials,
                                                              const u32 *__restrict__ err, double *__restrict__ pos) {
     __shared__ double wave_tot[SCAN_THREADS / 64];
+    // A lane scans SCAN_ITEMS consecutive weights, but global memory is read and written with
+    // consecutive lanes on consecutive elements (a lane-contiguous 64-byte access pattern makes every
+    // load touch 64 cache lines: that alone held this kernel at 2.5 TB/s); the tile changes shape in
+    // LDS, one pad word per 8 so that the lane-contiguous side is conflict-free.
+    static_assert(SCAN_ITEMS == 8, "pad of the LDS tile");
+    __shared__ double tile[SCAN_TILE + SCAN_TILE / 8];
     const u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
     // a sort pass that gave up waiting (k_onesweep) must not pass for a result
     double carry = *err ? __longlong_as_double(0x7FF8000000000000ll) : partials[blockIdx.x];
     for (u64 t0 = lo; t0 < hi; t0 += SCAN_TILE) {
-        // lane owns SCAN_ITEMS consecutive keys
-        const u64 i0 = t0 + (u64)threadIdx.x * SCAN_ITEMS;
+        double k[SCAN_ITEMS];
+#pragma unroll
+        for (int r = 0; r < SCAN_ITEMS; ++r) {
+            const u64 i = t0 + (u64)(r * SCAN_THREADS) + threadIdx.x;
+            k[r] = i < hi ? keys[i] : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < SCAN_ITEMS; ++r) {
+            const u32 e = r * SCAN_THREADS + threadIdx.x;
+            const u64 i = t0 + e;
+            tile[e + (e >> 3)] = i < hi ? exp2(k[r] - logn) : 0.0;
+        }
+        __syncthreads();
+        double *mine = tile + threadIdx.x * (SCAN_ITEMS + 1);  // == pad(threadIdx.x * 8 + j) for SCAN_ITEMS == 8
         double w[SCAN_ITEMS];
         double s = 0.0;
 #pragma unroll
         for (int j = 0; j < SCAN_ITEMS; ++j) {
-            w[j] = (i0 + j < hi) ? exp2(keys[i0 + j] - logn) : 0.0;
-            s += w[j];
+            s += mine[j];
             w[j] = s;  // inclusive within the lane
         }
         double tot;
         const double excl = block_exclusive_scan(s, wave_tot, tot);
 #pragma unroll
-        for (int j = 0; j < SCAN_ITEMS; ++j)
-            if (i0 + j < hi) pos[i0 + j] = carry + (excl + w[j]);
+        for (int j = 0; j < SCAN_ITEMS; ++j) mine[j] = carry + (excl + w[j]);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SCAN_ITEMS; ++r) {
+            const u32 e = r * SCAN_THREADS + threadIdx.x;
+            const u64 i = t0 + e;
+            if (i < hi) pos[i] = tile[e + (e >> 3)];
+        }
         carry += tot;
+        __syncthreads();  // the next tile overwrites `tile`
     }
 }
 
@@ -408,6 +470,34 @@ __global__ void __launch_bounds__(256) k_query(const double *__restrict__ keys, 
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// The onesweep variant in use: workgroup shape (threads x keys per lane = tile) and where the next
+// tile's keys are requested (0: at the top of its own iteration, 1: before the look-back, 2: after
+// it).  Tuning knobs (MC_SORT_VARIANT, MC_SORT_PREFETCH, read once); results never depend on them.
+typedef void (*onesweep_fn)(const Plan *, int, const u64 *, u64 *, u64 *, u64, u32, const u32 *, u32 *, u64 *);
+struct SortVariant {
+    onesweep_fn fn;
+    int threads, items, prefetch;
+};
+template <int T, int I, int W>
+SortVariant onesweep_pick(int prefetch) {
+    onesweep_fn f = prefetch == 1 ? k_onesweep<T, I, 1, W> : prefetch == 2 ? k_onesweep<T, I, 2, W> : k_onesweep<T, I, 0, W>;
+    return SortVariant{f, T, I, prefetch};
+}
+const SortVariant &sort_variant() {
+    static const SortVariant v = [] {
+        const int which = getenv("MC_SORT_VARIANT") ? atoi(getenv("MC_SORT_VARIANT")) : 0;
+        int pf = getenv("MC_SORT_PREFETCH") ? atoi(getenv("MC_SORT_PREFETCH")) : 0;
+        pf = pf >= 0 && pf <= 2 ? pf : 0;
+        // (every variant here compiles without register spills: the ones that needed scratch memory
+        // were slower, and the one run of such a kernel beside k_score on a second queue faulted)
+        switch (which) {
+        case 7: return onesweep_pick<384, 16, 2>(pf);   // 6144 keys, 6 waves
+        default: return onesweep_pick<256, 24, 2>(0);   // 6144 keys, 4 waves; 2 workgroups per CU (its prefetching forms spill)
+        }
+    }();
+    return v;
+}
+
 // Workgroups of k_onesweep the current device holds at once (its look-back relies on the whole grid
 // being resident): the occupancy API's answer, capped by what the kernel's LDS allows.
 int onesweep_resident_workgroups(int *out) {
@@ -418,11 +508,15 @@ int onesweep_resident_workgroups(int *out) {
     if (!cached[dev]) {
         int per_cu = 0, n_cu = 0;
         hipFuncAttributes attr;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_onesweep, SORT_THREADS, 0));
-        HIP_TRY(hipFuncGetAttributes(&attr, (const void *)k_onesweep));
+        const void *fn = (const void *)sort_variant().fn;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, sort_variant().threads, 0));
+        HIP_TRY(hipFuncGetAttributes(&attr, fn));
         HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
         const int by_lds = attr.sharedSizeBytes ? (int)(160 * 1024 / attr.sharedSizeBytes) : per_cu;
         if (by_lds < per_cu) per_cu = by_lds;
+        if (getenv("MC_SORT_WG_PER_CU") && atoi(getenv("MC_SORT_WG_PER_CU")) > 0 &&
+            atoi(getenv("MC_SORT_WG_PER_CU")) < per_cu)
+            per_cu = atoi(getenv("MC_SORT_WG_PER_CU"));
         if (per_cu < 1 || n_cu < 1) {
             mc_set_error("k_onesweep does not fit a compute unit (occupancy %d, %d CUs)", per_cu, n_cu);
             return MC_ERR_HIP;
@@ -433,7 +527,7 @@ int onesweep_resident_workgroups(int *out) {
     return MC_OK;
 }
 
-u32 sort_tiles(u64 n) { return (u32)((n + SORT_TILE - 1) / SORT_TILE); }
+u32 sort_tiles(u64 n, u64 tile) { return (u32)((n + tile - 1) / tile); }
 constexpr size_t HIST_WORDS = 8 * 256 + 8 + 8;  // histograms, spare, error word (+pad)
 u32 scan_blocks(u64 n) {
     u64 tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
@@ -444,7 +538,7 @@ u32 scan_blocks(u64 n) {
 
 extern "C" size_t mc_rank_workspace_bytes(uint64_t n) {
     return align256(n * sizeof(u64)) + align256(HIST_WORDS * sizeof(u32)) +
-           align256((size_t)2 * sort_tiles(n) * 256 * sizeof(u64)) + align256(sizeof(Plan)) +
+           align256((size_t)2 * sort_tiles(n, SORT_TILE_MIN) * 256 * sizeof(u64)) + align256(sizeof(Plan)) +
            align256(SCAN_MAX_BLOCKS * sizeof(double));
 }
 
@@ -469,7 +563,8 @@ extern "C" int mc_rank_build(const double *keys_in, uint64_t n, uint64_t n_globa
     SortWs ws;
     ws.temp = (u64 *)p;
     p += align256(n * sizeof(u64));
-    const u32 tiles = sort_tiles(n);
+    const SortVariant &sv = sort_variant();
+    const u32 tiles = sort_tiles(n, (u64)sv.threads * sv.items);
     const size_t lb_bytes = (size_t)2 * tiles * 256 * sizeof(u64);
     ws.hist = (u32 *)p;
     p += align256(HIST_WORDS * sizeof(u32));
@@ -500,8 +595,8 @@ extern "C" int mc_rank_build(const double *keys_in, uint64_t n, uint64_t n_globa
     }
     const u32 os_grid = tiles < (u32)resident ? tiles : (u32)resident;
     for (int pass = 0; pass < 8; ++pass)
-        hipLaunchKernelGGL(k_onesweep, dim3(os_grid), dim3(SORT_THREADS), 0, s, ws.plan, pass, in, A, B, (u64)n, tiles,
-                           (const u32 *)ws.hist, err, ws.lookback);
+        hipLaunchKernelGGL(sv.fn, dim3(os_grid), dim3(sv.threads), 0, s, (const Plan *)ws.plan, pass, in, A, B, (u64)n,
+                           tiles, (const u32 *)ws.hist, err, ws.lookback);
     // positions
     const double logn = std::log2((double)n_global);
     const u32 sb = scan_blocks(n);

@@ -24,9 +24,15 @@ for i in range(10):
     DeviceRank(keys, workspace=ws, keys_sorted=ks, positions=pos); ev[i + 1].record()
 torch.cuda.synchronize()
 ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(10))
-ok = bool((ks[1:] >= ks[:-1]).all())
+ok = bool(torch.equal(ks.view(torch.int64), torch.sort(keys)[0].view(torch.int64)))
 print(json.dumps({"ms_med": ts[5], "ms_min": ts[0], "sorted": ok}))
 """ % ROOT
-r = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, timeout=300)
-print(f"rc={r.returncode} {r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-1500:]}", flush=True)
-sys.exit(r.returncode)
+variants = sys.argv[1].split(",") if len(sys.argv) > 1 else ["0"]
+prefetch = sys.argv[2].split(",") if len(sys.argv) > 2 else ["0"]
+for v in variants:
+    for pf in prefetch:
+        env = dict(os.environ, MC_SORT_VARIANT=v, MC_SORT_PREFETCH=pf)
+        r = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, timeout=300, env=env)
+        print(f"variant={v} prefetch={pf} rc={r.returncode} {r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-1500:]}", flush=True)
+        if r.returncode != 0:
+            sys.exit(r.returncode)

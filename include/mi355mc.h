@@ -242,6 +242,15 @@ void mc_counts_free(mc_counts *k);
 int mc_counts_merge(mc_counts *k, const char *utf8, size_t bytes, uint32_t splitter_cp, uint32_t start4word,
                     uint32_t skip4word, uint32_t max_gram, uint32_t threshold, uint32_t start_cp, uint32_t end_cp);
 int mc_counts_train(const mc_counts *k, uint32_t threshold, mc_trained **out);
+/* Counts that exist as plain arrays -- the `(counts, words, config)` pickle the reference writes per round
+ * (backwords_secondary_main.py:28-32, 215-217) and reads back (backwords_secondary_trainer.py:36-42,
+ * backwords_secondary_simulator.py:17) -- into an EMPTY mc_counts, so that resumed rounds merge and train
+ * natively.  Symbols (texts as code points) keep the order given, `words` and the rows keep theirs (dict
+ * insertion order); the row of the empty context is implied by `words` and is not passed. */
+int mc_counts_import(mc_counts *k, const uint32_t *sym_text_off, const uint32_t *sym_text, uint32_t n_sym,
+                     const uint32_t *word_sym, const uint64_t *word_cnt, uint32_t n_words, const uint32_t *ctx_off,
+                     const uint32_t *ctx_units, const uint64_t *row_off, const uint32_t *ent_sym,
+                     const uint64_t *ent_cnt, uint32_t n_rows, uint32_t start_cp, uint32_t end_cp);
 int64_t mc_counts_array(const mc_counts *k, int what, void *dst, size_t cap);
 /* mc_table_compile on the trained rows (kind MC_KIND_NGRAM with order = n-1, or MC_KIND_BACKOFF). */
 int mc_trained_compile(const mc_trained *t, uint32_t kind, uint32_t order, uint32_t min_len, uint32_t max_len,

@@ -8,6 +8,11 @@ from .._counting import float_sum, read_lines, row_total, split_line, transition
 from .backwords_trainer import group_by_length
 
 
+# plain-dict models (pickles) are taken over by the native trainer when they are well-formed; tests
+# switch this off to keep the dict-based restatement of the reference beside it
+IMPORT_PLAIN_COUNTS = True
+
+
 def parse_line(line: str, splitter: str, start4words: int, step4words: int):
     return split_line(line, splitter, start4words, step4words)
 
@@ -18,6 +23,12 @@ def backwords_counter(nwords_list, splitter: str, start_chr: str, end_chr: str,
                       words: Dict[str, int] = None):
     from ..trained import NativeCounts, one_code_point, splitter_code_point
     sig = (splitter_code_point(splitter), one_code_point(start_chr), one_code_point(end_chr))
+    if IMPORT_PLAIN_COUNTS and None not in sig and isinstance(nwords_dict, dict) and nwords_dict and words:
+        # a model that comes as plain dicts (a pickle of an earlier run, the reference's or ours) resumes on
+        # the native path when it has the shape the secondary trainer builds
+        native = NativeCounts.from_plain(nwords_dict, words, start_chr, end_chr)
+        if native is not None:
+            nwords_dict = native
     if None not in sig and (nwords_dict is None or (isinstance(nwords_dict, NativeCounts)
                                                     and nwords_dict.signature in (None, sig))):
         # native path (csrc/mc_train.cpp): the counts live in C++ and are merged there

@@ -15,6 +15,9 @@ class BackWordsSecondaryMonteCarlo(BackWordsMonteCarlo):
     def __init__(self, model, max_iter: int = 10 ** 100):
         super().__init__(None)
         counts, words, config = model if isinstance(model, tuple) else pickle.load(model)
+        if not isinstance(counts, NativeCounts):
+            # plain dicts (a pickle written by the reference or by this package): native when well-formed
+            counts = NativeCounts.from_plain(counts, words, config['start_chr'], config['end_chr']) or counts
         if isinstance(counts, NativeCounts):
             # freq2prob and the table compile in C++ (csrc/mc_train.cpp), no Python dict in between
             self._trained = counts.train(config['threshold'])

@@ -522,6 +522,64 @@ extern "C" int mc_counts_merge(mc_counts *k, const char *utf8, size_t bytes, uin
     return MC_OK;
 }
 
+// A count model that exists as plain arrays -- a `(counts, words, config)` pickle written by the
+// reference (backwords_secondary_main.py:28-32) or by this package -- back into native counts, so
+// that later rounds merge and train in C++.  Symbols keep the order given; the row of the empty
+// context is implied by `words` (the caller checks that the pickle's agrees) and is not passed.
+extern "C" int mc_counts_import(mc_counts *k, const uint32_t *sym_text_off, const uint32_t *sym_text, uint32_t n_sym,
+                                const uint32_t *word_sym, const uint64_t *word_cnt, uint32_t n_words,
+                                const uint32_t *ctx_off, const uint32_t *ctx_units, const uint64_t *row_off,
+                                const uint32_t *ent_sym, const uint64_t *ent_cnt, uint32_t n_rows, uint32_t start_cp,
+                                uint32_t end_cp) {
+    if (!k || !sym_text_off || (n_words && (!word_sym || !word_cnt)) ||
+        (n_rows && (!ctx_off || !row_off || !ent_sym || !ent_cnt))) {
+        mc_set_error("mc_counts_import: bad argument");
+        return MC_ERR_ARG;
+    }
+    if (!k->c.syms.text.empty() || !k->table.rows.empty()) {
+        mc_set_error("mc_counts_import: the counts are not empty");
+        return MC_ERR_ARG;
+    }
+    Corpus &c = k->c;
+    for (uint32_t i = 0; i < n_sym; ++i) {
+        const Seq t(sym_text + sym_text_off[i], sym_text + sym_text_off[i + 1]);
+        if (c.syms.get(t) != i) {
+            *k = mc_counts();
+            mc_set_error("mc_counts_import: symbol %u repeats an earlier one", i);
+            return MC_ERR_ARG;
+        }
+    }
+    c.start_sym = c.syms.get(Seq{start_cp});
+    c.end_sym = c.syms.get(Seq{end_cp});
+    const uint32_t known = (uint32_t)c.syms.text.size();
+    bool ok = true;
+    for (uint32_t i = 0; i < n_words && ok; ++i) {
+        ok = word_sym[i] < known && c.word_pos.emplace(word_sym[i], i).second;
+        c.word_sym.push_back(word_sym[i]);
+        c.word_cnt.push_back(word_cnt[i]);
+    }
+    for (uint32_t r = 0; r < n_rows && ok; ++r) {
+        const uint32_t n = ctx_off[r + 1] - ctx_off[r];
+        for (uint32_t j = 0; j < n; ++j) ok = ok && ctx_units[ctx_off[r] + j] < known;
+        ok = ok && n > 0 && k->table.find(ctx_units + ctx_off[r], n) == MC_NONE;
+        if (!ok) break;
+        const uint32_t row = k->table.row_of(ctx_units + ctx_off[r], n);
+        for (uint64_t e = row_off[r]; e < row_off[r + 1] && ok; ++e) {
+            ok = ent_sym[e] < known;
+            if (ok) k->table.add(row, ent_sym[e], ent_cnt[e]);
+        }
+        ok = ok && k->table.rows[row].sym.size() == row_off[r + 1] - row_off[r];  // (no symbol twice in a row)
+    }
+    if (!ok) {
+        *k = mc_counts();
+        mc_set_error("mc_counts_import: inconsistent arrays (unknown symbol id, repeated word, context or transition, "
+                     "or an empty context among the rows)");
+        return MC_ERR_ARG;
+    }
+    k->any_line = n_words > 0;
+    return MC_OK;
+}
+
 namespace {
 // the zero-gram row of nwords_dict: every symbol but the start symbol, counted per occurrence (:49-54)
 Row zero_row(const Corpus &c) {

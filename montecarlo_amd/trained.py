@@ -118,6 +118,58 @@ class NativeCounts(collections.abc.Mapping):
             nv.lib.mc_counts_free(h)
             self._h = None
 
+    @classmethod
+    def from_plain(cls, counts: Dict, words: Dict[str, int], start_chr: str, end_chr: str) -> Optional["NativeCounts"]:
+        """The reference's plain ``{context: {symbol: count}}`` + ``words`` (what a model pickle holds,
+        backwords_secondary_main.py:28-32) as native counts (mc_counts_import), or None when the dicts
+        are not what the secondary trainer builds (the row of the empty context must be ``words``
+        without the start symbol, counts must be non-negative ints): the caller then keeps the dicts."""
+        start_cp, end_cp = one_code_point(start_chr), one_code_point(end_chr)
+        if start_cp is None or end_cp is None or not isinstance(counts, dict) or not isinstance(words, dict):
+            return None
+        zero = {s: c for s, c in words.items() if s != start_chr}
+        have = counts.get((), {} if not words else None)
+        if have is None or list(have.items()) != list(zero.items()):
+            return None
+        sym_id: Dict[str, int] = {}
+        try:
+            for s in words:
+                sym_id.setdefault(s, len(sym_id))
+            rows = [(ctx, row) for ctx, row in counts.items() if ctx != ()]
+            for ctx, row in rows:
+                for s in ctx:
+                    sym_id.setdefault(s, len(sym_id))
+                for s in row:
+                    sym_id.setdefault(s, len(sym_id))
+            if not all(isinstance(s, str) for s in sym_id):
+                return None
+            text = "".join(sym_id).encode("utf-32-le", "surrogatepass")
+            text_off = np.zeros(len(sym_id) + 1, dtype=np.uint32)
+            np.cumsum(np.fromiter((len(s) for s in sym_id), dtype=np.uint32, count=len(sym_id)), out=text_off[1:])
+            a = {
+                "text_off": text_off, "text": np.frombuffer(text + b"\0\0\0\0", dtype="<u4"),
+                "word_sym": np.fromiter((sym_id[s] for s in words), dtype=np.uint32, count=len(words)),
+                "word_cnt": np.fromiter(words.values(), dtype=np.uint64, count=len(words)),
+                "ctx_off": np.zeros(len(rows) + 1, dtype=np.uint32),
+                "row_off": np.zeros(len(rows) + 1, dtype=np.uint64),
+            }
+            np.cumsum(np.fromiter((len(c) for c, _ in rows), dtype=np.uint32, count=len(rows)), out=a["ctx_off"][1:])
+            np.cumsum(np.fromiter((len(r) for _, r in rows), dtype=np.uint64, count=len(rows)), out=a["row_off"][1:])
+            a["ctx_units"] = np.fromiter((sym_id[s] for c, _ in rows for s in c), dtype=np.uint32,
+                                         count=int(a["ctx_off"][-1]))
+            a["ent_sym"] = np.fromiter((sym_id[s] for _, r in rows for s in r), dtype=np.uint32,
+                                       count=int(a["row_off"][-1]))
+            a["ent_cnt"] = np.fromiter((v for _, r in rows for v in r.values()), dtype=np.uint64,
+                                       count=int(a["row_off"][-1]))
+        except (TypeError, ValueError, OverflowError, AttributeError):
+            return None
+        out = cls()
+        vp = lambda x: x.ctypes.data_as(C.c_void_p)  # noqa: E731
+        rc = nv.lib.mc_counts_import(out._h, vp(a["text_off"]), vp(a["text"]), len(sym_id), vp(a["word_sym"]),
+                                     vp(a["word_cnt"]), len(words), vp(a["ctx_off"]), vp(a["ctx_units"]),
+                                     vp(a["row_off"]), vp(a["ent_sym"]), vp(a["ent_cnt"]), len(rows), start_cp, end_cp)
+        return out if rc == 0 else None
+
     def merge(self, text: str, splitter_cp: int, start4word: int, skip4word: int, max_gram: int, threshold: int,
               start_cp: int, end_cp: int):
         data = text.encode("utf-8", "surrogatepass")

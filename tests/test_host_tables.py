@@ -239,12 +239,17 @@ def test_native_secondary_counts_equal_python(train_char):
     from montecarlo_amd.backwords.backwords_secondary_trainer import freq2prob
     from montecarlo_amd.lib4mc.ProbLib import expand_2d
     from montecarlo_amd.trained import NativeCounts
+    import montecarlo_amd.backwords.backwords_secondary_trainer as sec_mod
     rounds = [train_char[:1500], train_char[1500:1900] + ["", "zz"], [], train_char[1900:2000]]
     nat = natw = py = pyw = None
     py, pyw = {}, {}
     for lines in rounds:
         nat, natw = secondary_counter(list(lines), "", "\x03", "\x00", 0, 1, 256, 3, nwords_dict=nat, words=natw)
-        py, pyw = secondary_counter(list(lines), "", "\x03", "\x00", 0, 1, 256, 3, nwords_dict=py, words=pyw)
+        sec_mod.IMPORT_PLAIN_COUNTS = False            # the dict-based trainer, as the comparison
+        try:
+            py, pyw = secondary_counter(list(lines), "", "\x03", "\x00", 0, 1, 256, 3, nwords_dict=py, words=pyw)
+        finally:
+            sec_mod.IMPORT_PLAIN_COUNTS = True
         assert isinstance(nat, NativeCounts) and not isinstance(py, NativeCounts)
         assert [(k, list(v.items())) for k, v in nat.items()] == [(k, list(v.items())) for k, v in py.items()]
         assert list(natw.items()) == list(pyw.items())
@@ -254,6 +259,55 @@ def test_native_secondary_counts_equal_python(train_char):
         assert rows_of(m.nwords) == rows_of(expand_2d(freq2prob(py, 3)))
     back = pickle.loads(pickle.dumps((nat, natw, cfg)))
     assert type(back[0]) is dict and back[0] == py
+
+
+def test_reference_pickle_resumes_natively(train_char):
+    """A model pickle written by the REFERENCE's secondary trainer (tests/golden/make_golden_pickle.py:
+    plain dicts) loads into native counts (mc_counts_import): the simulator built from it has the
+    reference's round-0 table, the next round merges in C++ and ends at the reference's round-1 counts
+    and table; a pickle of ours resumes the same way; dicts that are not a trainer's stay dicts."""
+    import pickle
+    from conftest import GOLDEN
+    from montecarlo_amd.trained import NativeCounts
+    fx = golden("secondary_thr4_char.json")
+    with open(os.path.join(GOLDEN, "secondary_round0_reference.pickle"), "rb") as fd:
+        m = BackWordsSecondaryMonteCarlo(fd)
+    assert hasattr(m, "_trained")                       # freq2prob + compile ran in C++
+    check_table(fx["round0"], m)
+    with open(os.path.join(GOLDEN, "secondary_round0_reference.pickle"), "rb") as fd:
+        counts, words, cfg = pickle.load(fd)
+    assert type(counts) is dict
+    nat = NativeCounts.from_plain(counts, words, cfg["start_chr"], cfg["end_chr"])
+    assert [(k, list(v.items())) for k, v in nat.items()] == [(k, list(v.items())) for k, v in counts.items()]
+    assert list(nat.words().items()) == list(words.items())
+    counts1, words1 = secondary_counter(train_char[2500:3200], "", "\x03", "\x00", 0, 1, 256, 4, nwords_dict=counts,
+                                        words=words)
+    assert isinstance(counts1, NativeCounts)
+    assert digest([[list(k), sorted(v.items())] for k, v in counts1.items()]) == fx["meta"]["counts_digest"]
+    m1 = BackWordsSecondaryMonteCarlo((counts1, words1, cfg))
+    check_table(fx["round1"], m1)
+    # our own pickle of round 0 -> plain dicts -> native again -> same round 1
+    back = pickle.loads(pickle.dumps((nat, nat.words(), cfg)))
+    counts2, words2 = secondary_counter(train_char[2500:3200], "", "\x03", "\x00", 0, 1, 256, 4, nwords_dict=back[0],
+                                        words=back[1])
+    assert isinstance(counts2, NativeCounts) and dict(counts2) == dict(counts1) and words2 == words1
+    # not a trainer's dicts: the empty-context row disagrees with `words` / a count is not an integer
+    bad = {k: dict(v) for k, v in counts.items()}
+    bad[()]["a"] = bad[()].get("a", 0) + 1
+    assert NativeCounts.from_plain(bad, words, "\x03", "\x00") is None
+    odd = {k: dict(v) for k, v in counts.items()}
+    odd[next(k for k in odd if k)]["zz"] = "many"
+    assert NativeCounts.from_plain(odd, words, "\x03", "\x00") is None
+    # ... and the raw entry point refuses inconsistent arrays
+    h = ctypes.c_void_p()
+    nv.check(nv.lib.mc_counts_new(ctypes.byref(h)))
+    off = np.array([0, 1, 2], dtype=np.uint32)
+    txt = np.array([3, 0], dtype=np.uint32)
+    wsym, wcnt = np.array([0, 7], dtype=np.uint32), np.array([1, 1], dtype=np.uint64)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    rc = nv.lib.mc_counts_import(h, vp(off), vp(txt), 2, vp(wsym), vp(wcnt), 2, None, None, None, None, None, 0, 3, 0)
+    assert rc < 0 and b"inconsistent" in nv.lib.mc_last_error()
+    nv.lib.mc_counts_free(h)
 
 
 def test_compile_rejects_bad_tables():

@@ -50,7 +50,7 @@ def main(out):
         rank_kernels = ("k_hist_all", "k_plan", "k_copy_if_unsorted", "k_onesweep", "k_weight_sums", "k_scan_partials",
                         "k_positions")
         latest = {"k_sample": total(lambda k: k.startswith("k_sample")),
-                  "mc_rank_build": total(lambda k: k in rank_kernels),
+                  "mc_rank_build": total(lambda k: k.split("<")[0] in rank_kernels),
                   "k_score": total(lambda k: k.startswith("k_score")), "k_query": total(lambda k: k == "k_query"),
                   "note": "HBM bytes per bench step (FETCH_SIZE x2 per MI355X_MICROARCH.md + WRITE_SIZE), rocprofv3 --pmc"}
         res["_per_step"] = latest

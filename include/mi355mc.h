@@ -365,6 +365,29 @@ int mc_rank_build(const double *keys_in, uint64_t n, uint64_t n_global, double *
 int mc_rank_query(const double *keys_sorted, const double *positions, uint64_t n, const double *x, uint64_t t,
                   double *out_pos, uint64_t *out_cnt, void *stream);
 
+/* ---- threshold enumeration ------------------------------------------------------------------*/
+/* Replaces the recursive enumerators (nwords/nwords_enumerator.py:15-42 `enumerator`/`iterate` for a
+ * MC_KIND_NGRAM model, backwords/backwords_enumerator.py:15-45 for MC_KIND_BACKOFF): every string whose
+ * -log2 p (summed in path order, fp64) is < threshold, closed by the end symbol at cur_len >= min_len, in
+ * the order the reference's depth-first loop writes them.  A node with cur_len > max_len is not expanded
+ * (30 and 256 in the two references).  Fixed order: an end symbol before min_len is dropped; backoff: it is
+ * appended and the walk continues from the context the table gives (the reference's behaviour, kept).
+ * Runs as a level-by-level frontier expansion on the model's GPU; the levels are library-owned device
+ * buffers, at most `max_nodes` nodes in total (MC_ERR_NOMEM beyond).  Synchronises `stream`. */
+typedef struct mc_enum_result mc_enum_result;
+enum {
+    MC_ENUM_ML2P = 0, /* double[n_out]            -log2 p of every written string                  */
+    MC_ENUM_LEN = 1,  /* uint32[n_out]            its length in symbols                            */
+    MC_ENUM_SYMS = 2  /* uint32[n_out * stride]   its symbol ids (row-major, `stride` per string)  */
+};
+int mc_enumerate(const mc_model *m, double threshold, uint32_t min_len, uint32_t max_len, uint64_t max_nodes,
+                 void *stream, mc_enum_result **out);
+/* info[0..3] = strings written, stride of MC_ENUM_SYMS, nodes expanded, levels */
+int mc_enum_info(const mc_enum_result *r, uint64_t info[4]);
+/* copies up to `cap` bytes to HOST memory `dst`, returns the full size in bytes */
+int64_t mc_enum_fetch(const mc_enum_result *r, int what, void *dst, size_t cap);
+void mc_enum_free(mc_enum_result *r);
+
 #ifdef __cplusplus
 }
 #endif

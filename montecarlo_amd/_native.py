@@ -29,6 +29,7 @@ DRAW_DIRECT, DRAW_ONE, DRAW_MULTI = 0, 1, 2
 (TRAINED_CTX_OFF, TRAINED_CTX_UNITS, TRAINED_ROW_OFF, TRAINED_ENT_SYM, TRAINED_ENT_PROB, TRAINED_ENT_CUM,
  TRAINED_ENT_ML2P, TRAINED_SYM_TEXT_OFF, TRAINED_SYM_TEXT, TRAINED_WORD_SYM, TRAINED_WORD_COUNT) = range(11)
 LINES_COUNT, LINES_OFF, LINES_CPS, LINES_INFO = range(4)
+ENUM_ML2P, ENUM_LEN, ENUM_SYMS = range(3)
 COUNTS_ENT_COUNT = 16
 ERR_DIVERGED = -5
 
@@ -89,6 +90,10 @@ def _load() -> C.CDLL:
         "mc_trained_free": (None, [vp]),
         "mc_trained_array": (C.c_int64, [vp, C.c_int, vp, C.c_size_t]),
         "mc_trained_compile": (C.c_int, [vp] + [C.c_uint32] * 6 + [C.POINTER(vp)]),
+        "mc_enumerate": (C.c_int, [vp, C.c_double, C.c_uint32, C.c_uint32, C.c_uint64, vp, C.POINTER(vp)]),
+        "mc_enum_info": (C.c_int, [vp, u64p]),
+        "mc_enum_fetch": (C.c_int64, [vp, C.c_int, vp, C.c_size_t]),
+        "mc_enum_free": (None, [vp]),
         "mc_lines_ingest": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(vp)]),
         "mc_lines_free": (None, [vp]),
         "mc_lines_array": (C.c_int64, [vp, C.c_int, vp, C.c_size_t]),
@@ -117,7 +122,8 @@ lib = _load()
 EXPORTS = ["mc_abi_version", "mc_last_error", "mc_table_compile", "mc_table_free", "mc_table_array", "mc_table_info",
            "mc_ctx_hash", "mc_text_hash", "mc_score_words_workspace_bytes", "mc_score_words", "mc_score_bpe", "mc_train_nwords", "mc_train_backwords", "mc_trained_free", "mc_counts_new", "mc_counts_free",
            "mc_counts_merge", "mc_counts_train", "mc_counts_import", "mc_counts_array", "mc_trained_array", "mc_trained_compile", "mc_lines_ingest", "mc_lines_free", "mc_lines_array", "mc_model_upload", "mc_model_destroy", "mc_model_check", "mc_sample", "mc_sample_injected", "mc_sample_dedup",
-           "mc_score", "mc_rank_workspace_bytes", "mc_rank_build", "mc_rank_query"]
+           "mc_score", "mc_rank_workspace_bytes", "mc_rank_build", "mc_rank_query", "mc_enumerate", "mc_enum_info", "mc_enum_fetch",
+           "mc_enum_free"]
 
 
 def check(rc: int) -> int:

@@ -933,6 +933,17 @@ extern "C" int mc_model_upload(const mc_table *t, int device, mc_model **out) {
     return MC_OK;
 }
 
+int mc_model_enum_view(const mc_model *m, mc_enum_view *out) {
+    if (!m || !out) {
+        mc_set_error("null model");
+        return MC_ERR_ARG;
+    }
+    const DevModel &d = m->dev;
+    *out = mc_enum_view{(const mc_state_rec *)d.state, (const mc_payload *)d.payload, d.sym_chars, d.start_state,
+                        d.root, d.n_ctx, d.n_sym, d.end_sym, d.kind, m->device};
+    return MC_OK;
+}
+
 extern "C" void mc_model_destroy(mc_model *m) {
     if (!m) return;
     if (m->arena) (void)hipFree(m->arena);

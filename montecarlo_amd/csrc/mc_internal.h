@@ -53,3 +53,13 @@ struct mc_table {
 void mc_set_error(const char *fmt, ...);
 uint64_t mc_trans_hash(uint64_t key);
 size_t mc_table_device_bytes(const mc_table *t);
+
+// what the enumeration kernels (mc_enum.hip) read of a resident model (defined in mc_device.hip)
+struct mc_enum_view {
+    const mc_state_rec *state;
+    const mc_payload *payload;
+    const uint32_t *sym_chars;
+    uint32_t start_state, root, n_ctx, n_sym, end_sym, kind;
+    int device;
+};
+int mc_model_enum_view(const mc_model *m, mc_enum_view *out);

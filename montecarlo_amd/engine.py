@@ -149,6 +149,29 @@ class DeviceModel:
         return res
 
 
+    def enumerate(self, threshold: float, min_len: int, max_len: int, max_nodes: int = 1 << 31):
+        """Threshold enumeration (mc_enumerate): (ml2p, lengths, symbol rows) of every string with
+        -log2 p < threshold, as numpy arrays in the reference's depth-first order."""
+        h = C.c_void_p()
+        with torch.cuda.device(self.tdev):
+            nv.check(nv.lib.mc_enumerate(self._h, float(threshold), min_len, max_len, max_nodes, self._stream(),
+                                         C.byref(h)))
+        try:
+            info = (C.c_uint64 * 4)()
+            nv.check(nv.lib.mc_enum_info(h, info))
+            n, stride = int(info[0]), int(info[1])
+            ml2p = np.empty(n, dtype=np.float64)
+            lens = np.empty(n, dtype=np.uint32)
+            syms = np.empty((n, stride), dtype=np.uint32)
+            for what, arr in ((nv.ENUM_ML2P, ml2p), (nv.ENUM_LEN, lens), (nv.ENUM_SYMS, syms)):
+                if arr.nbytes:
+                    nv.check(nv.lib.mc_enum_fetch(h, what, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+            self.last_enum_info = {"strings": n, "stride": stride, "nodes": int(info[2]), "levels": int(info[3])}
+        finally:
+            nv.lib.mc_enum_free(h)
+        return ml2p, lens, syms
+
+
 class DeviceRank:
     """Sorted keys + positions on one GPU (MonteCarloLib.__init__, lib4mc/MonteCarloLib.py:10-28)."""
 

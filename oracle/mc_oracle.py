@@ -12,6 +12,7 @@ keyed by tuple contexts, numpy fp64 cumulative sums), the algorithms of
   backwords/backwords_trainer.py:23-78            backoff counter
   backwords/backwords_secondary_trainer.py:23-121 count merge + freq2prob
   nwords_v2/nwords_trainer_v2.py:12-56            v2 counter
+  nwords/nwords_enumerator.py:15-42, backwords/backwords_enumerator.py:15-45   threshold enumerators
   nwords_simulator.py:30-116, backwords_simulator.py:28-49,
   nwords_simulator_v2.py:60-82, bpe_simulator.py:17-150, bpeX/modelreader.py:15-68
 
@@ -583,3 +584,53 @@ class RankOracle:
     def format_gc(gc) -> str:
         return "".join(f"{pwd}\t{x:.8f}\t{c}\t{rank}\t{cracked}\t{ratio:5.2f}\n"
                        for pwd, x, c, rank, cracked, ratio in gc)
+
+
+# --------------------------------------------------------------------------- threshold enumerators
+def enumerate_strings(table: Dict, threshold: float, start_chr: str, end_chr: str, min_len: int, order: int = None):
+    """nwords/nwords_enumerator.py:15-42 (``order`` given: context = last ``order`` symbols, a node with
+    cur_len > 30 is not expanded, an end symbol never recurses) and backwords/backwords_enumerator.py:15-45
+    (``order`` None: context = longest suffix that is a row, cur_len > 256, an end symbol met before
+    min_len is appended and the walk goes on).  ``table`` holds probabilities; returns the list of
+    (string, -log2 p) in the order the reference writes them.  The recursion is an explicit stack of
+    (history, sum, length, iterator over the row)."""
+    ml2p = {ctx: [(s, -math.log2(p)) for s, p in row.items()] for ctx, row in table.items()}
+    backoff = order is None
+    limit = 256 if backoff else 30
+
+    def row_of(hist: Tuple):
+        if not backoff:
+            return ml2p[hist[-order:]]                    # KeyError as in the reference (:26)
+        for i in range(len(hist) + 1):
+            if hist[i:] in ml2p:
+                return ml2p[hist[i:]]
+        raise KeyError(hist)
+
+    out: List[Tuple[str, float]] = []
+    lead = 1 if backoff else order
+    root = (start_chr,) * lead
+    stack = []
+
+    def enter(hist, acc, length):
+        row = row_of(hist)
+        if length > limit or acc >= threshold:
+            return
+        stack.append((hist, acc, length, iter(row)))
+
+    enter(root, 0.0, 0)
+    while stack:
+        hist, acc, length, it = stack[-1]
+        step = next(it, None)
+        if step is None:
+            stack.pop()
+            continue
+        sym, m = step
+        new = acc + m
+        if not new < threshold:
+            continue
+        if sym == end_chr and (length >= min_len or not backoff):
+            if length >= min_len:
+                out.append(("".join(hist[lead:]), new))
+            continue
+        enter(hist + (sym,), new, length + len(sym))
+    return out

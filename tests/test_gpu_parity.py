@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import fh, golden, golden_lines, hx
+from conftest import fh, golden, golden_lines, hx  # noqa: F401
 from montecarlo_amd import synth
 from montecarlo_amd.backwords.backwords_secondary_trainer import backwords_counter as secondary_counter
 from montecarlo_amd.backwords_secondary_simulator import BackWordsSecondaryMonteCarlo
@@ -466,6 +466,61 @@ def test_distribution_vs_reference_sampler(train_char):
     table = np.vstack([a[keep], b[keep]])
     chi = stats.chi2_contingency(table)
     assert chi[1] > 1e-3, chi[:2]
+
+
+@pytest.mark.parametrize("case", ["nwords_n3_char", "nwords_n4_char_min6", "nwords_n2_tab", "backwords_thr10_char",
+                                  "backwords_thr3_char_min7", "backwords_thr3_tab"])
+def test_enumerators_match_reference(case, train_char, train_tab):
+    """nwords_enumerator.enumerator / backwords_enumerator.enumerator on the GPU write, byte for byte, what
+    the reference's recursive enumerators wrote (order, strings incl. the appended early end symbols,
+    5/8-decimal formatting) and leave -log2 p in the caller's dict as they do."""
+    import hashlib
+    import math
+    from montecarlo_amd.backwords.backwords_enumerator import enumerator as back_enum
+    from montecarlo_amd.backwords.backwords_trainer import backwords_counter
+    from montecarlo_amd.nwords.nwords_enumerator import enumerator as nw_enum
+    from montecarlo_amd.nwords.nwords_trainer import nwords_counter
+    fx = golden("enumerators.json")[case]
+    lines = train_char if fx["train"] == "train_char.txt" else train_tab
+    buf = io.StringIO()
+    if fx["kind"] == "nwords":
+        probs, _ = nwords_counter(synth.as_file(lines), fx["n"], fx["splitter"], fx["end_chr"], 0, 1,
+                                  start_chr=fx["start_chr"])
+        first = next(iter(next(iter(probs.values())).values()))
+        nw_enum(probs, threshold=fx["threshold"], start_chr=fx["start_chr"], end_chr=fx["end_chr"],
+                min_len=fx["min_len"], f_save=buf, order=fx["n"] - 1)
+    else:
+        probs, _ = backwords_counter(synth.as_file(lines), fx["splitter"], fx["start_chr"], fx["end_chr"], 0, 1,
+                                     fx["count_threshold"], 256)
+        first = next(iter(next(iter(probs.values())).values()))
+        back_enum(probs, fx["threshold"], fx["start_chr"], fx["end_chr"], fx["min_len"], buf)
+    assert next(iter(next(iter(probs.values())).values())) == -math.log2(first)
+    text = buf.getvalue()
+    got = text.split("\n")[:-1]
+    assert len(got) == fx["n_lines"]
+    if "lines" in fx:
+        assert got == fx["lines"]
+    assert hashlib.sha256(text.encode("utf-8", "surrogatepass")).hexdigest() == fx["sha256"]
+
+
+def test_enumeration_at_scale_matches_oracle(big_model):
+    """The 100k-line backoff model enumerated to a threshold that yields ~1e5..1e6 strings: the same strings
+    and sums, in the same order, as the CPU restatement of the reference's recursion; the node limit is
+    an error, not a truncation."""
+    from montecarlo_amd import _native as nv
+    from oracle import mc_oracle as orc
+    m, _ = big_model
+    probs = {ctx: {k: vals[k] for k in keys} for ctx, (vals, keys, cum) in m.nwords.items()}
+    thr = 24.0
+    want = orc.enumerate_strings(probs, thr, "\x00", "\x03", 4)
+    ml2p, lens, syms = m._dev.enumerate(thr, 4, 256)
+    assert len(ml2p) == len(want) > 50000
+    got_s = m._flat.decode(syms, lens)
+    assert got_s == [w[0] for w in want]
+    assert np.array_equal(ml2p.view(np.uint64), np.array([w[1] for w in want]).view(np.uint64))
+    assert bool((ml2p < thr).all())
+    with pytest.raises(nv.NativeError, match="max_nodes"):
+        m._dev.enumerate(thr, 4, 256, max_nodes=1000)
 
 
 def golden_path(name):

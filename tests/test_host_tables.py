@@ -341,3 +341,51 @@ def test_native_line_ingest_equals_dict_counting():
     with pytest.raises(nv.NativeError):
         h = ctypes.c_void_p()
         nv.check(nv.lib.mc_lines_ingest(b"ok\n\xff\xfe\n", 6, ctypes.byref(h)))
+
+
+ENUM_CASES = ["nwords_n3_char", "nwords_n4_char_min6", "nwords_n2_tab", "backwords_thr10_char",
+              "backwords_thr3_char_min7", "backwords_thr3_tab"]
+
+
+def enum_model(fx, train_char, train_tab):
+    """(probability table, FlatTable as the product's enumerator builds it) for a golden enumerator case."""
+    from montecarlo_amd.backwords.backwords_trainer import backwords_counter
+    from montecarlo_amd.lib4mc.ProbLib import expand_2d
+    from montecarlo_amd.nwords.nwords_trainer import nwords_counter
+    from montecarlo_amd.tables import FlatTable
+    lines = train_char if fx["train"] == "train_char.txt" else train_tab
+    if fx["kind"] == "nwords":
+        probs, _ = nwords_counter(synth.as_file(lines), fx["n"], fx["splitter"], fx["end_chr"], 0, 1,
+                                  start_chr=fx["start_chr"])
+        flat = FlatTable(expand_2d(probs), nv.KIND_NGRAM, order=fx["n"] - 1,
+                         start_units=(fx["start_chr"],) * (fx["n"] - 1), end_chr=fx["end_chr"], min_len=fx["min_len"])
+    else:
+        probs, _ = backwords_counter(synth.as_file(lines), fx["splitter"], fx["start_chr"], fx["end_chr"], 0, 1,
+                                     fx["count_threshold"], 256)
+        flat = FlatTable(expand_2d(probs), nv.KIND_BACKOFF, order=0, start_units=(fx["start_chr"],),
+                         end_chr=fx["end_chr"], min_len=fx["min_len"])
+    return probs, flat
+
+
+def check_enum_text(fx, text):
+    lines = text.split("\n")[:-1]
+    assert len(lines) == fx["n_lines"]
+    if "lines" in fx:
+        assert lines == fx["lines"]
+    else:
+        assert lines[:200] == fx["head"] and lines[-200:] == fx["tail"]
+    assert hashlib.sha256(text.encode("utf-8", "surrogatepass")).hexdigest() == fx["sha256"]
+
+
+@pytest.mark.parametrize("case", ENUM_CASES)
+def test_enumeration_walk_over_compiled_table(case, train_char, train_tab):
+    """The expansion rule of mc_enumerate (tests/walker.py steps state/payload as k_enum_expand does),
+    depth first, writes what the reference's enumerators wrote: pins the next-state links the kernel
+    relies on, the end symbol's included."""
+    fx = golden("enumerators.json")[case]
+    _, flat = enum_model(fx, train_char, train_tab)
+    backoff = fx["kind"] == "backwords"
+    found = CompiledWalker(flat).enumerate(fx["threshold"], fx["min_len"], 256 if backoff else 30, backoff)
+    digits = 5 if backoff else 8
+    text = "".join("%s\t%.*f\n" % ("".join(flat.symbols[s] for s in syms), digits, x) for syms, x in found)
+    check_enum_text(fx, text)

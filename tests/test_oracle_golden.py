@@ -180,3 +180,36 @@ def test_c_oracle_rank():
     qp, qc = c_oracle.rank_query(srt, want, x)
     for (xx, w), p, c in zip(fx["probes"], qp, qc):
         assert hx(p if c > 0 else 1) == w
+
+
+def enum_text(found, digits):
+    return "".join(f"{pwd}\t{x:.{digits}f}\n" for pwd, x in found)
+
+
+def check_enum_text(fx, text):
+    lines = text.split("\n")[:-1]
+    assert len(lines) == fx["n_lines"]
+    if "lines" in fx:
+        assert lines == fx["lines"]
+    else:
+        assert lines[:200] == fx["head"] and lines[-200:] == fx["tail"]
+    assert hashlib.sha256(text.encode("utf-8", "surrogatepass")).hexdigest() == fx["sha256"]
+
+
+@pytest.mark.parametrize("case", ["nwords_n3_char", "nwords_n4_char_min6", "nwords_n2_tab", "backwords_thr10_char",
+                                  "backwords_thr3_char_min7", "backwords_thr3_tab"])
+def test_enumerators(case, train_char, train_tab):
+    """oracle.enumerate_strings == what the reference's enumerators wrote (tests/golden/make_golden_enum.py)."""
+    fx = golden("enumerators.json")[case]
+    lines = train_char if fx["train"] == "train_char.txt" else train_tab
+    if fx["kind"] == "nwords":
+        probs, _ = orc.train_nwords(lines, fx["n"], fx["splitter"], fx["end_chr"], start_chr=fx["start_chr"])
+        found = orc.enumerate_strings(probs, fx["threshold"], fx["start_chr"], fx["end_chr"], fx["min_len"],
+                                      order=fx["n"] - 1)
+        check_enum_text(fx, enum_text(found, 8))
+    else:
+        probs, _ = orc.train_backwords(lines, fx["splitter"], fx["start_chr"], fx["end_chr"], 0, 1,
+                                       fx["count_threshold"], 256)
+        found = orc.enumerate_strings(probs, fx["threshold"], fx["start_chr"], fx["end_chr"], fx["min_len"])
+        check_enum_text(fx, enum_text(found, 5))
+        assert fx["early_end_lines"] > 0          # the appended-end-symbol behaviour is in the vectors

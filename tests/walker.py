@@ -227,3 +227,30 @@ class CompiledWalker:
             if ok and p < 1022.0 and p < best:
                 best = p
         return best
+
+
+    # mirrors mc_enumerate (csrc/mc_enum.hip): the same expansion rule over state/payload, depth first
+    def enumerate(self, threshold, min_len, max_len, backoff):
+        out = []
+        n_ctx = len(self.state)
+
+        def expand(st, acc, ln, syms):
+            if ln > max_len or acc >= threshold:
+                return
+            row = self.state[st]
+            for j in range(int(row["len"])):
+                p = self.payload[int(row["ent_off"]) + j]
+                na = acc + float(p["ml2p"])
+                if not na < threshold:
+                    continue
+                end, s = bool(int(p["sym"]) >> 31), int(p["sym"]) & 0x7FFFFFFF
+                if end and (ln >= min_len or not backoff):
+                    if ln >= min_len:
+                        out.append((list(syms), na))
+                    continue
+                nxt = int(p["next"])
+                assert nxt < n_ctx, "context without a row"
+                expand(nxt, na, ln + int(self.sym_chars[s]), syms + [s])
+
+        expand(self.start, 0.0, 0, [])
+        return out

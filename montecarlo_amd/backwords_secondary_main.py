@@ -9,7 +9,13 @@ cracked passwords (``samples`` strategy: the test passwords whose STRING was sam
 
 Reproducibility: every round's model draws its Philox seed from ``random.getrandbits(64)`` on first
 use, so ``random.seed(x)`` before ``wrapper()`` fixes the whole run (tests/golden/make_golden_secondary.py
-pins it against the reference run with the same streams injected)."""
+pins it against the reference run with the same streams injected).
+
+Multi-GPU (config 5 on 8 GPUs): launched through ``torch.distributed.run`` every rank runs this same
+driver; ``montecarlo_amd.dist.use_group`` shards each round's sampling over the ranks (global sample
+ids: the sample set, the cracked sets and every output file are those of a single-GPU run), the
+``sampled_pwds`` dict is merged over the ranks and the guess-number queries are all-reduced; rank 0
+writes the result files, the other ranks write theirs into a scratch directory."""
 import argparse
 import json
 import math
@@ -126,8 +132,34 @@ def plan_rounds(strategy: List[str], size: int):
     return [(GN_CAP, GN_CAP)] * rounds, [f"samples-{size}"] * rounds, True
 
 
+def join_ranks() -> int:
+    """Under torch.distributed.run (WORLD_SIZE > 1): one rank per GPU over RCCL -- or, when the box has
+    fewer GPUs than ranks (a rehearsal), shared GPUs over gloo -- and sharding switched on.  Returns
+    this process's rank (0 when not distributed)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0
+    import torch
+    import torch.distributed as dist
+    from . import dist as mcd
+    if not dist.is_initialized():
+        local, n_dev = int(os.environ.get("LOCAL_RANK", "0")), torch.cuda.device_count()
+        if n_dev >= int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            torch.cuda.set_device(local % max(n_dev, 1))
+            dist.init_process_group("gloo")
+    mcd.use_group(True)
+    return dist.get_rank()
+
+
 def wrapper(argv=None):
     args = build_cli().parse_args(argv)
+    rank = join_ranks()
+    if rank != 0:
+        import tempfile
+        args.save = tempfile.mkdtemp(prefix=f"mc-rank{rank}-")       # only rank 0's files are the result
     permits = {'guesses', 'hits', 'samples', 'auto_hits'}
     if args.strategy[0] not in permits:
         print(f"strategy should be one of `{', '.join(permits)}`", file=sys.stderr)

@@ -11,13 +11,63 @@ are implied by the positions).  Samples never move between GPUs.
 
 Backend: torch.distributed -- "nccl" is RCCL over xGMI on the GPU box, "gloo" in
 the CPU tests.  T <= 1e6 test passwords is 8 MB: latency-bound, one bucket.
+
+`use_group` makes the sharding ambient for the lib4mc classes: ``MonteCarlo.sample`` then draws only
+this rank's share of the sample ids (the ids are global, so the sample SET is the one a single GPU
+draws), ``sampled_pwds`` is merged over the ranks in global first-sampled order, and
+``MonteCarloLib`` all-reduces its queries -- a driver written against the reference's surface
+(backwords_secondary_main.py, BASELINE config 5) runs unchanged on every rank.
 """
 from __future__ import annotations
 
-from typing import Tuple
+import random
+from typing import Dict, List, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
+
+_ACTIVE = None      # the process group MonteCarlo.sample / MonteCarloLib shard over (None: one GPU)
+
+
+def use_group(group=True):
+    """Shard every later ``sample`` / ``MonteCarloLib`` over ``group`` (True: the default group; None:
+    back to one GPU).  The ranks must make the same calls in the same order; their ``random`` states
+    are made equal here (rank 0's), because the reference's drivers draw the Philox seed and
+    ``random.sample`` from it."""
+    global _ACTIVE
+    if group is None or group is False:
+        _ACTIVE = None
+        return
+    _ACTIVE = dist.group.WORLD if group is True else group
+    if dist.get_world_size(_ACTIVE) > 1:
+        box = [random.getstate() if dist.get_rank(_ACTIVE) == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(_ACTIVE, 0), group=_ACTIVE)
+        random.setstate(box[0])
+
+
+def active_group():
+    """The ambient group if it has more than one rank, else None."""
+    if _ACTIVE is not None and dist.is_initialized() and dist.get_world_size(_ACTIVE) > 1:
+        return _ACTIVE
+    return None
+
+
+def merge_distinct(local: Sequence[Tuple[str, float, int]], group) -> List[Tuple[str, float, int]]:
+    """Every rank's distinct sampled strings ``(string, ml2p, occurrences)`` -- each list in its shard's
+    first-sampled order, shards being contiguous id ranges in rank order -- as ONE list in global
+    first-sampled order with the occurrences summed: what ``sample(size, sampled_pwds)`` builds on a
+    single GPU (lib4mc/MonteCarloParent.py:39-45), on every rank."""
+    parts: List = [None] * dist.get_world_size(group)
+    dist.all_gather_object(parts, list(local), group=group)
+    seen: Dict[str, List] = {}
+    for part in parts:
+        for pwd, x, c in part:
+            hit = seen.get(pwd)
+            if hit is None:
+                seen[pwd] = [x, c]
+            else:
+                hit[1] += c
+    return [(pwd, x, c) for pwd, (x, c) in seen.items()]
 
 
 def shard_range(n_global: int, rank: int, world: int) -> Tuple[int, int]:

@@ -21,6 +21,8 @@ class MonteCarloLib:
     def __init__(self, minus_log_prob_list, group=None, n_global: int = None):
         if isinstance(minus_log_prob_list, SampleKeys):
             keys = minus_log_prob_list.tensor
+            if group is None and minus_log_prob_list.group is not None:     # sharded sample(): its group and n
+                group, n_global = minus_log_prob_list.group, minus_log_prob_list.n_global
         elif torch.is_tensor(minus_log_prob_list):
             keys = minus_log_prob_list
         else:

@@ -16,6 +16,7 @@ from math import log2
 from typing import Dict, List, TextIO, Tuple, Union
 
 import numpy as np
+import torch
 
 from .FileLib import wc_l
 
@@ -26,9 +27,11 @@ class SampleKeys(collections.abc.Sequence):
     element access); ``MonteCarloLib`` consumes it without a host round trip.
     10^7..10^10 keys cannot be a Python list."""
 
-    def __init__(self, tensor):
+    def __init__(self, tensor, group=None, n_global: int = None):
         self.tensor = tensor
         self._host = None
+        # sharded sampling (montecarlo_amd.dist.use_group): this rank's share of n_global keys
+        self.group, self.n_global = group, n_global
 
     def __len__(self):
         return int(self.tensor.numel())
@@ -99,11 +102,21 @@ class MonteCarlo(metaclass=abc.ABCMeta):
         seed, first = self._claim_ids(size)
         want = isinstance(sampled_pwds, dict)
         stride = self._sample_stride() if want else 0
+        from .. import dist as mcd
+        group, n_global = mcd.active_group(), size
+        if group is not None:
+            # this rank's contiguous share of the SAME sample ids a single GPU would draw
+            lo, size = mcd.shard_range(n_global, torch.distributed.get_rank(group),
+                                       torch.distributed.get_world_size(group))
+            first += lo
         res = self._dev.sample(size, seed, first_id=first, max_draws=self.max_draws, sym_stride=stride)
         self._dev.check()
         if want:
             seen: Dict[str, List] = {}
-            for pwd, x, c in self._distinct_strings(res, size, seed, first):
+            distinct = self._distinct_strings(res, size, seed, first) if size else []
+            if group is not None:
+                distinct = mcd.merge_distinct(distinct, group)
+            for pwd, x, c in distinct:
                 hit = seen.get(pwd)
                 if hit is None:
                     seen[pwd] = [x, c]
@@ -112,7 +125,7 @@ class MonteCarlo(metaclass=abc.ABCMeta):
             if clearIfNotNone:
                 sampled_pwds.clear()
             sampled_pwds.update(seen)
-        return SampleKeys(res["ml2p"])
+        return SampleKeys(res["ml2p"], group=group, n_global=n_global if group is not None else None)
 
     def _sample_stride(self) -> int:
         """Symbols kept per sample when strings are wanted (longer ones are replayed one by one)."""

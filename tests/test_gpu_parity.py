@@ -170,10 +170,7 @@ def test_secondary_main_matches_reference_run(tmp_path):
     """BASELINE config 5: `backwords_secondary_main --strategy samples 2` end to end (count merge ->
     model -> sample with strings -> rank -> score -> cracked set -> next round) against the output
     files of the reference's own run with the same streams (golden/secondary_main.json)."""
-    import hashlib
-    import json
     import os
-    import pickle
     import random
     from conftest import GOLDEN
     from montecarlo_amd import backwords_secondary_main as main
@@ -182,37 +179,8 @@ def test_secondary_main_matches_reference_run(tmp_path):
     random.seed(fx["meta"]["seed"])
     main.wrapper(["-i", os.path.join(GOLDEN, fx["meta"]["train"]), "-t", os.path.join(GOLDEN, fx["meta"]["test"]),
                   "-s", save] + fx["meta"]["args"])
-    assert sorted(os.listdir(save)) == sorted(fx["files"])
-    for name, want in fx["files"].items():
-        path = os.path.join(save, name)
-        if name.endswith(".pickle"):
-            with open(path, "rb") as f:
-                counts, _words, _cfg = pickle.load(f)                  # written by this test
-            rows = [[list(k), sorted(v.items())] for k, v in counts.items()]
-            assert hashlib.sha256(json.dumps(rows, ensure_ascii=True).encode()).hexdigest() == want, name
-        elif name == "config.json":
-            with open(path) as f:
-                cfg = json.load(f)
-            cfg["training_list"] = cfg["training_list"][1:]
-            assert cfg == want
-        elif name in ("iter_result.txt", "sectional_result.txt"):
-            # guess numbers come from the prefix sums (1e-9 relative, ceil may flip on an exact integer)
-            with open(path, newline="") as f:
-                got_lines = f.read().split("\n")
-            want_lines = want.split("\n")
-            assert len(got_lines) == len(want_lines)
-            inexact = 0
-            for g, w in zip(got_lines, want_lines):
-                if g == w:
-                    continue
-                gc, wc = g.split("\t"), w.split("\t")
-                assert gc[:3] == wc[:3] and gc[4:] == wc[4:], (g, w)
-                assert abs(int(gc[3]) - int(wc[3])) <= REL * int(wc[3]) + 1, (g, w)
-                inexact += 1
-            assert inexact <= 2, name
-        else:
-            with open(path, newline="") as f:
-                assert f.read() == want, name
+    from secondary_check import check_saved
+    check_saved(save, fx)
 
 
 def test_plugin_surface_matches_reference_run(train_char):

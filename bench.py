@@ -23,6 +23,11 @@ import time
 import numpy as np
 import torch
 
+if "--rehearse-on-one-gpu" in sys.argv:
+    # ranks sharing one GPU: the sort takes its tiles by ticket (csrc/mc_rank.hip: a fixed assignment needs the
+    # whole grid resident, which two processes on one GPU deny each other); read once when the library loads
+    os.environ.setdefault("MC_SORT_TICKETS", "1")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("TQDM_DISABLE", "1")
@@ -70,6 +75,9 @@ def main():
                     help="samples of the CPU baseline leg (default: the whole workload, about 10-20 s of one core)")
     args = ap.parse_args()
 
+    if os.environ.get("BENCH_TRACE_AFTER"):                 # debugging aid: where is every thread after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["BENCH_TRACE_AFTER"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -100,7 +108,11 @@ def main():
     positions = torch.empty_like(keys)
     ws = torch.empty(nv.lib.mc_rank_workspace_bytes(N), dtype=torch.uint8, device=dev)
     t_ml2p = torch.empty(T, dtype=torch.float64, device=dev)
-    q_pos = torch.empty(T, dtype=torch.float64, device=dev)
+    # two result buffers and a stream of its own for the collective: a step's all-reduce runs beside the
+    # next step's sampling (world > 1); the main stream only waits for it when the buffer comes round again
+    q_pos = [torch.empty(T, dtype=torch.float64, device=dev) for _ in range(2)]
+    reduced = [None, None]
+    comm = torch.cuda.Stream(device=dev) if world > 1 else None
     q_cnt = torch.empty(T, dtype=torch.int64, device=dev)
     seed = 20250304
 
@@ -112,6 +124,10 @@ def main():
         """sample -> rank build on the main stream; the test set is scored on a second stream while
         the rank build runs (it does not depend on the samples); the queries join the two."""
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
+        slot = it & 1
+        if reduced[slot] is not None:
+            main_stream.wait_event(reduced[slot])           # this buffer's all-reduce of two steps ago
+            reduced[slot] = None
         first = (it * world + rank) * N                     # disjoint Philox sample ids per rank and step
         marks[0].record()
         dm.sample(N, seed, first_id=first, out=keys)
@@ -133,8 +149,21 @@ def main():
         else:
             main_stream.wait_event(marks[4])
         marks[5].record()
-        rk.query(t_ml2p, out_pos=q_pos, out_cnt=q_cnt)
-        mcd.combine_positions(q_pos)                        # ONE RCCL all-reduce (8 MB); no-op on one GPU
+        rk.query(t_ml2p, out_pos=q_pos[slot], out_cnt=q_cnt)
+        if comm is not None:
+            # ONE RCCL all-reduce (8 MB) per step, on the collective's stream behind the queries
+            asked = torch.cuda.Event()
+            asked.record(main_stream)
+            comm.wait_event(asked)
+            if args.rehearse_on_one_gpu:
+                # gloo stages GPU tensors through the host on a stream of its own; entered with this
+                # process's kernels still queued while the other rank computes on the same GPU it was
+                # seen to stall (both ranks inside all_reduce, neither finishing).  Idle the GPU first.
+                torch.cuda.synchronize()
+            with torch.cuda.stream(comm):
+                mcd.combine_positions(q_pos[slot])
+                reduced[slot] = torch.cuda.Event()
+                reduced[slot].record(comm)
         marks[6].record()
         if timed:
             ev["sample"].append((marks[0], marks[1]))
@@ -143,7 +172,7 @@ def main():
             ev["query"].append((marks[5], marks[6]))
 
     def fence():
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()                            # (every stream of the device: the collective's too)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

@@ -40,7 +40,7 @@ constexpr int SORT_TILE_MIN = 4096;  // smallest tile any variant uses: sizes th
 constexpr unsigned long long LB_LOCAL = 1ull << 62;  // count of this tile alone
 constexpr unsigned long long LB_INCL = 2ull << 62;   // count of this tile and every earlier one
 constexpr unsigned long long LB_MASK = (1ull << 62) - 1;
-constexpr unsigned int LB_SPIN_LIMIT = 1u << 24;     // a bound, not a protocol: see k_onesweep
+constexpr unsigned int LB_SPIN_LIMIT = 1u << 23;     // a bound, not a protocol: see k_onesweep
 constexpr int LB_WINDOW = 4;                         // predecessors read per look-back step
 constexpr int HIST_COPIES = 4, HIST_PITCH = 8 * 256 + 1;
 constexpr int HIST_PLAIN = 5;  // digits counted without looking for wave-wide agreement
@@ -178,11 +178,17 @@ __global__ void __launch_bounds__(256) k_copy_if_unsorted(const Plan *__restrict
 // be made resident without anyone else finishing, and it waits for nothing: the look-back cannot
 // deadlock whatever order the hardware dispatches in.  (A ticket counter would give the same
 // guarantee, but 2,441 atomics on one address cost 13 us per pass: same-address atomics serialise
-// at ~11 ns each.)  The spin is nevertheless bounded; if the bound is ever hit the error word is
+// at ~11 ns each.)  That argument needs the GPU to itself: when ANOTHER process holds part of the GPU
+// with a grid of the same kind (two ranks rehearsing on one GPU), each can be left with half a grid
+// resident that waits for the half that cannot start.  TICKETS is the variant for a shared GPU
+// (MC_SORT_TICKETS=1): tiles are taken from a counter in increasing order, two ahead so that nobody
+// waits for the counter, and the lowest unfinished tile is then always held by a running workgroup
+// whatever is resident; measured +21 us per pass at 1e7 keys, which is why it is not the default.
+// The spin is nevertheless bounded; if the bound is ever hit the error word is
 // set and k_positions poisons the output with NaN (loud, not a hang).  Look-back words are written
 // and read with agent-scope atomics (the per-XCD L2s are not coherent with each other); nothing
 // else crosses workgroups.
-template <int THREADS, int ITEMS, int PREFETCH, int WAVES>
+template <int THREADS, int ITEMS, int PREFETCH, int WAVES, bool TICKETS = false>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, 8)))
 k_onesweep(const Plan *__restrict__ plan, int pass, const u64 *in, u64 *a, u64 *b, u64 n, u32 tiles,
            const u32 *__restrict__ hist, u32 *err, u64 *lookback) {
@@ -198,6 +204,8 @@ k_onesweep(const Plan *__restrict__ plan, int pass, const u64 *in, u64 *a, u64 *
     __shared__ u32 tile_off[256];  // exclusive scan of the tile's digit counts
     __shared__ u32 wave_sum[4];
     __shared__ u32 wave_below[4];
+    __shared__ u32 ticket_s[2];
+    u32 *ticket = err - 8 + pass;  // (TICKETS) the pass's counter among the spare words before the error word
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     // each wave owns 64 * ITEMS consecutive keys of the tile: order = (wave, round, lane).  The 256
     // digits belong to the first 256 lanes (waves 0..3).
@@ -211,10 +219,20 @@ k_onesweep(const Plan *__restrict__ plan, int pass, const u64 *in, u64 *a, u64 *
             k[r] = j < tile_n ? src[t0 + j] : ~0ull;
         }
     };
-    if (PREFETCH) load_tile(blockIdx.x, nkey);
-    for (u32 tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    u32 tile = blockIdx.x, tile1 = blockIdx.x + gridDim.x, ahead = 0;
+    if (TICKETS) {
+        if (tid == 0) {
+            ticket_s[0] = atomicAdd(ticket, 1u);
+            ticket_s[1] = atomicAdd(ticket, 1u);
+        }
+        __syncthreads();
+        tile = ticket_s[0];
+        tile1 = ticket_s[1];
+    }
+    if (PREFETCH) load_tile(tile, nkey);
+    while (tile < tiles) {
     for (int i = tid; i < NW * 256; i += THREADS) (&wcnt[0][0])[i] = 0;
-    __syncthreads();  // (also: every wave has left the previous tile's write-out)
+    __syncthreads();  // (also: every wave has left the previous tile's write-out and read ticket_s)
     const u64 t0 = (u64)tile * TILE;
     const u32 tile_n = (u32)min((u64)TILE, n - t0);
     if (tid < 256) lb_next[(u64)tile * 256 + tid] = 0;  // the next active pass starts from clean words
@@ -246,8 +264,9 @@ k_onesweep(const Plan *__restrict__ plan, int pass, const u64 *in, u64 *a, u64 *
         old = __shfl(old, leader < 0 ? 0 : leader);
         rank[r] = old + before;
     }
+    if (TICKETS && tid == 0) ahead = atomicAdd(ticket, 1u);  // the tile after next; read at the end of this one
     // the next tile's keys travel while this tile waits for its predecessors and writes out
-    if (PREFETCH == 1) load_tile(tile + gridDim.x, nkey);
+    if (PREFETCH == 1) load_tile(tile1, nkey);
     __syncthreads();
     u32 tot = 0, inc = 0, ginc = 0, gown = 0;
     u64 *mine = lb + (u64)tile * 256 + (tid & 255);
@@ -323,7 +342,7 @@ k_onesweep(const Plan *__restrict__ plan, int pass, const u64 *in, u64 *a, u64 *
         }
         base[tid] = (u64)(gbelow + ginc - gown) + excl;
     }
-    if (PREFETCH == 2) load_tile(tile + gridDim.x, nkey);
+    if (PREFETCH == 2) load_tile(tile1, nkey);
     __syncthreads();
     // stage keys in LDS in digit order
 #pragma unroll
@@ -335,6 +354,7 @@ k_onesweep(const Plan *__restrict__ plan, int pass, const u64 *in, u64 *a, u64 *
             if (at < (u32)TILE) stage[at] = key[r]; else atomicOr(err, 2u);
         }
     }
+    if (TICKETS && tid == 0) ticket_s[0] = ahead;
     __syncthreads();
     // digit-contiguous runs out to global
     for (u32 j = tid; j < tile_n; j += THREADS) {
@@ -345,6 +365,8 @@ k_onesweep(const Plan *__restrict__ plan, int pass, const u64 *in, u64 *a, u64 *
         const u64 at = base[d] + (j - tile_off[d]);
         if (at < n) dst[at] = k; else atomicOr(err, 2u);
     }
+    tile = tile1;
+    tile1 = TICKETS ? ticket_s[0] : tile1 + gridDim.x;
     }  // next tile of this workgroup
 }
 
@@ -485,13 +507,15 @@ SortVariant onesweep_pick(int prefetch) {
 }
 const SortVariant &sort_variant() {
     static const SortVariant v = [] {
-        const int which = getenv("MC_SORT_VARIANT") ? atoi(getenv("MC_SORT_VARIANT")) : 0;
+        const int tickets = getenv("MC_SORT_TICKETS") ? atoi(getenv("MC_SORT_TICKETS")) : 0;
+        const int which = tickets ? 8 : getenv("MC_SORT_VARIANT") ? atoi(getenv("MC_SORT_VARIANT")) : 0;
         int pf = getenv("MC_SORT_PREFETCH") ? atoi(getenv("MC_SORT_PREFETCH")) : 0;
         pf = pf >= 0 && pf <= 2 ? pf : 0;
         // (every variant here compiles without register spills: the ones that needed scratch memory
         // were slower, and the one run of such a kernel beside k_score on a second queue faulted)
         switch (which) {
         case 7: return onesweep_pick<384, 16, 2>(pf);   // 6144 keys, 6 waves
+        case 8: return SortVariant{k_onesweep<256, 24, 0, 2, true>, 256, 24, 0};  // tiles by ticket (shared GPU)
         default: return onesweep_pick<256, 24, 2>(0);   // 6144 keys, 4 waves; 2 workgroups per CU (its prefetching forms spill)
         }
     }();

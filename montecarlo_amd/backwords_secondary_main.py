@@ -87,32 +87,34 @@ def secondary_cracker(backwords, words, config, func_threshold: Tuple[int, int],
     return counts, words, config, next_training, max_gn
 
 
+# the reference's command line (backwords_secondary_main.py:92-133): flag, dest, type, default, help
+_FILE_FLAGS = (
+    ("-i", "--training", "training", argparse.FileType('r'), "training passwords, one per line"),
+    ("-t", "--testing", "testing", argparse.FileType('r'), "test passwords, one per line"),
+    ("-s", "--save", "save", str, "folder that receives every result file"),
+)
+_OPTIONS = (
+    ("--size", "size", int, 100000, "Monte Carlo samples per round"),
+    ("--secondary-sample", "secondary_sample", int, 10000000000,
+     "upper bound on the cracked passwords that feed the next round (drawn with random.sample beyond it)"),
+    ("--splitter", "splitter", str, "empty", "column separator of the input: empty | space | tab | a literal"),
+    ("--start4word", "start4words", int, 0, "column of the first word"),
+    ("--skip4word", "skip4words", int, 1, "step from one word column to the next (tags sit between them)"),
+    ("--max-gram", "max_gram", int, 256, "longest context"),
+    ("--threshold", "threshold", int, 10, "counts below it are pruned"),
+    ("--max-iter", "max_iter", int, 10 ** 20, "bound on the segmentations tried by calc_ml2p"),
+)
+
+
 def build_cli() -> argparse.ArgumentParser:
     cli = argparse.ArgumentParser('Backwords secondary main')
-    cli.add_argument("-i", "--training", dest="training", type=argparse.FileType('r'), required=True,
-                     help="The training file, each password a line")
-    cli.add_argument("-t", "--testing", dest="testing", type=argparse.FileType('r'), required=True,
-                     help="The testing file, each password a line")
-    cli.add_argument("-s", "--save", dest="save", required=True, type=str,
-                     help="A folder, results will be saved in this folder")
+    for short, flag, dest, kind, text in _FILE_FLAGS:
+        cli.add_argument(short, flag, dest=dest, type=kind, required=True, help=text)
     cli.add_argument("--strategy", dest="strategy", required=True, type=str, nargs="+",
-                     help="`guesses <g1> <g2> ...` guess number thresholds per round; `hits <h1> <h2> ...` cracked "
-                          "passwords per round; `auto_hits <factor> <base> <termination>`; `samples <rounds>` "
-                          "rounds of Monte Carlo simulation whose sampled strings are the guesses")
-    cli.add_argument("--size", dest="size", type=int, required=False, default=100000, help="sample size")
-    cli.add_argument("--secondary-sample", dest="secondary_sample", type=int, required=False, default=10000000000,
-                     help="use some of the cracked passwords for secondary training.")
-    cli.add_argument("--splitter", dest="splitter", type=str, required=False, default="empty",
-                     help="column separator of the input file: \"empty\" for '', \"space\" for ' ', \"tab\" for '\\t'")
-    cli.add_argument("--start4word", dest="start4words", type=int, required=False, default=0,
-                     help="index of the first word among the columns of a line")
-    cli.add_argument("--skip4word", dest="skip4words", type=int, required=False, default=1,
-                     help="step between words among the columns (to skip tags between them)")
-    cli.add_argument("--max-gram", dest="max_gram", required=False, type=int, default=256, help="max gram")
-    cli.add_argument("--threshold", dest="threshold", required=False, type=int, default=10,
-                     help="grams whose frequencies less than the threshold will be ignored")
-    cli.add_argument("--max-iter", dest="max_iter", required=False, default=10 ** 20, type=int,
-                     help="max iteration when calculating the maximum probability of a password")
+                     help="guesses <g1> <g2> ... | hits <h1> <h2> ... | auto_hits <factor> <base> <termination> | "
+                          "samples <rounds> (the sampled strings themselves are the guesses)")
+    for flag, dest, kind, default, text in _OPTIONS:
+        cli.add_argument(flag, dest=dest, type=kind, required=False, default=default, help=text)
     return cli
 
 

@@ -271,6 +271,11 @@ enum {
 int mc_lines_ingest(const char *utf8, size_t bytes, mc_lines **out);
 void mc_lines_free(mc_lines *l);
 int64_t mc_lines_array(const mc_lines *l, int what, void *dst, size_t cap);
+/* Replaces the formatting loop of MonteCarloLib.write2 (lib4mc/MonteCarloLib.py:65-68): one line
+ * "pwd\t%.8f\tappearance\trank\tcracked\t%5.2f\n" per password, the passwords given as one '\n'-separated
+ * UTF-8 text.  Returns the bytes written to dst (len(text) + 120 * n is always enough), negative on error. */
+int64_t mc_format_gc(const char *pwds_utf8, size_t bytes, uint64_t n, const double *mlp, const int64_t *appearance,
+                     const int64_t *rank, const int64_t *cracked, const double *ratio, char *dst, size_t cap);
 
 /* ---- device residency ---------------------------------------------------------------------*/
 /* Uploads the compiled table to GPU `device` (one hipMalloc arena). */

@@ -8,6 +8,7 @@
 // str.strip("\r\n") does.  A last line without '\n' counts; text ending in '\n' adds no empty line.
 #include "mc_internal.h"
 
+#include <cstdio>
 #include <cstring>
 
 namespace {
@@ -174,4 +175,45 @@ extern "C" int64_t mc_lines_array(const mc_lines *l, int what, void *dst, size_t
     }
     if (dst && cap) std::memcpy(dst, src, std::min(cap, bytes));
     return (int64_t)bytes;
+}
+
+// ---- result writer ---------------------------------------------------------------------------------
+// The formatting loop of MonteCarloLib.write2 (lib4mc/MonteCarloLib.py:65-68):
+//     f"{pwd}\t{mlp:.8f}\t{appearance}\t{rank}\t{cracked}\t{cracked_ratio:5.2f}\n"
+// for n passwords given as one '\n'-separated UTF-8 text.  printf's %.8f / %5.2f round the exact binary
+// value to nearest-even like Python's format().  Returns the bytes written, or MC_ERR_WORKSPACE when `cap`
+// is too small (len(text) + 120 * n always suffices).
+extern "C" int64_t mc_format_gc(const char *pwds_utf8, size_t bytes, uint64_t n, const double *mlp,
+                                const int64_t *appearance, const int64_t *rank, const int64_t *cracked,
+                                const double *ratio, char *dst, size_t cap) {
+    if ((bytes && !pwds_utf8) || (n && (!mlp || !appearance || !rank || !cracked || !ratio || !dst))) {
+        mc_set_error("mc_format_gc: bad argument");
+        return MC_ERR_ARG;
+    }
+    size_t at = 0, out = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        size_t end = at;
+        while (end < bytes && pwds_utf8[end] != '\n') ++end;
+        if (i + 1 < n && end >= bytes) {
+            mc_set_error("mc_format_gc: %llu passwords announced, the text holds %llu", (unsigned long long)n,
+                         (unsigned long long)(i + 1));
+            return MC_ERR_ARG;
+        }
+        const size_t len = end - at;
+        if (out + len + 120 > cap) {
+            mc_set_error("mc_format_gc: output buffer of %zu bytes is too small", cap);
+            return MC_ERR_WORKSPACE;
+        }
+        std::memcpy(dst + out, pwds_utf8 + at, len);
+        out += len;
+        const int w = std::snprintf(dst + out, 120, "\t%.8f\t%lld\t%lld\t%lld\t%5.2f\n", mlp[i], (long long)appearance[i],
+                                    (long long)rank[i], (long long)cracked[i], ratio[i]);
+        if (w < 0 || w >= 120) {
+            mc_set_error("mc_format_gc: a line's numbers do not fit 120 characters");
+            return MC_ERR_ARG;
+        }
+        out += (size_t)w;
+        at = end + 1;
+    }
+    return (int64_t)out;
 }

@@ -14,7 +14,7 @@ import numpy
 import torch
 
 from ..engine import DeviceRank
-from .MonteCarloParent import SampleKeys
+from .MonteCarloParent import SampleKeys, gc_paused
 
 
 class MonteCarloLib:
@@ -40,6 +40,7 @@ class MonteCarloLib:
         elif isinstance(minus_log_prob_list, list):
             minus_log_prob_list[:] = self.__rank.keys_sorted.cpu().numpy().tolist()
         self.__gc = None
+        self.__cols = None
 
     @property
     def device_rank(self) -> DeviceRank:
@@ -65,21 +66,38 @@ class MonteCarloLib:
         if need_resort:
             minus_log_prob_iter = sorted(minus_log_prob_iter, key=lambda x: x[2])
         items = list(minus_log_prob_iter)
+        self.__cols = None
         if not items:
             self.__gc = []
             return self.__gc
-        pwds = [t[0] for t in items]
-        apps = [t[1] for t in items]
-        mlps = [t[2] for t in items]
+        with gc_paused():
+            return self.__columns(items, add1)
+
+    def __columns(self, items, add1: bool):
+        pwds, apps, mlps = [t[0] for t in items], [t[1] for t in items], [t[2] for t in items]
         pos, cnt = self.__estimates(mlps)
         est = numpy.where(cnt > 0, pos, 1.0)
         ranks = _monotone_ranks(est, cnt, add1)
         total = sum(apps)
-        cracked, run = [], 0
-        for a in apps:
-            run += a
-            cracked.append(run)
-        gc = [(p, m, a, r, c, c / total * 100) for p, m, a, r, c in zip(pwds, mlps, apps, ranks, cracked)]
+        try:
+            running = numpy.cumsum(numpy.asarray(apps, dtype=numpy.int64))
+            exact = total < 2 ** 53 and running.size == len(apps)
+        except (OverflowError, TypeError, ValueError):
+            exact = False
+        if exact:
+            # c / total * 100 with both ints below 2^53: numpy's float64 division gives Python's quotient
+            ratio = running / float(total) * 100
+            cracked = running.tolist()
+            gc = list(zip(pwds, mlps, apps, ranks, cracked, ratio.tolist()))
+            # the columns write2 formats, kept while the list it returns is the one write2 sees
+            self.__cols = (pwds, numpy.asarray(mlps, dtype=numpy.float64), numpy.asarray(apps, dtype=numpy.int64),
+                           ranks, running, ratio)
+        else:
+            cracked, run = [], 0
+            for a in apps:
+                run += a
+                cracked.append(run)
+            gc = [(p, m, a, r, c, c / total * 100) for p, m, a, r, c in zip(pwds, mlps, apps, ranks, cracked)]
         self.__gc = gc
         return gc
 
@@ -88,25 +106,52 @@ class MonteCarloLib:
             raise Exception(f"{fd.name} is not writable")
         if self.__gc is None:
             raise Exception(f"run mlps2gc before invoke this method")
-        fd.writelines(f"{pwd}\t{mlp:.8f}\t{appearance}\t{rank}\t{cracked}\t{cracked_ratio:5.2f}\n"
-                      for pwd, mlp, appearance, rank, cracked, cracked_ratio in self.__gc)
+        text = _format_native(self.__gc, self.__cols)
+        self.__cols = None
+        if text is not None:
+            fd.write(text)
+        else:
+            fd.writelines(f"{pwd}\t{mlp:.8f}\t{appearance}\t{rank}\t{cracked}\t{cracked_ratio:5.2f}\n"
+                          for pwd, mlp, appearance, rank, cracked, cracked_ratio in self.__gc)
         self.__gc = None
 
 
-def _monotone_ranks(est: numpy.ndarray, cnt: numpy.ndarray, add1: bool) -> List[int]:
-    """rank_i = ceil(max(est_i, rank_{i-1} + add)), rank_0 = 0 (reference :47-55).
-    While every value is below 2^52 (float and int comparisons exact) this is a running
-    maximum; beyond that it is evaluated with the reference's own expression, whose
-    numpy-float-vs-int comparisons are themselves lossy there."""
-    if est.size and numpy.all(numpy.isfinite(est)) and float(est.max()) < 2.0 ** 52:
-        c = numpy.ceil(est).astype(numpy.int64)
-        if add1:
-            i = numpy.arange(1, c.size + 1, dtype=numpy.int64)
-            s = numpy.maximum.accumulate(numpy.maximum(c - i, 0))
-            return (s + i).tolist()
-        return numpy.maximum.accumulate(numpy.maximum(c, 0)).tolist()
-    out, prev, step = [], 0, 1 if add1 else 0
-    for e, k in zip(est, cnt):
-        prev = ceil(max(e if k > 0 else 1, prev + step))
-        out.append(prev)
-    return out
+def _format_native(gc, cols=None) -> "str | None":
+    """write2's lines through mc_format_gc (csrc/mc_ingest.cpp), or None when a row is not what it takes
+    (a components list instead of a string, a guess number beyond int64, a newline inside a password):
+    the f-string loop then writes them, as the reference does.  ``cols``: the columns ml2p_iter2gc
+    kept, used when the list still is the one it returned (same length, same first / middle / last row)."""
+    import ctypes as C
+
+    from .. import _native as nv
+    n = len(gc)
+    if n < 512:
+        return None
+    fresh = cols is not None and len(cols[0]) == n and all(
+        gc[i][0] is cols[0][i] and gc[i][3] == cols[3][i] and gc[i][1] == cols[1][i] for i in (0, n // 2, n - 1))
+    try:
+        if fresh:
+            pwds, mlp, apps, ranks, crk, ratio = cols
+            rank = numpy.asarray(ranks, dtype=numpy.int64)
+        else:
+            pwds = [row[0] for row in gc]
+            rank = numpy.fromiter((row[3] for row in gc), dtype=numpy.int64, count=n)
+            apps = numpy.fromiter((row[2] for row in gc), dtype=numpy.int64, count=n)
+            crk = numpy.fromiter((row[4] for row in gc), dtype=numpy.int64, count=n)
+            mlp = numpy.fromiter((row[1] for row in gc), dtype=numpy.float64, count=n)
+            ratio = numpy.fromiter((row[5] for row in gc), dtype=numpy.float64, count=n)
+        if not all(type(p) is str for p in pwds):
+            return None
+        blob = "\n".join(pwds).encode("utf-8")                 # (lone surrogates: not UTF-8, take the loop)
+    except (UnicodeEncodeError, OverflowError, TypeError, ValueError):
+        return None
+    if blob.count(b"\n") != n - 1:
+        return None
+    if not (numpy.isfinite(mlp).all() and numpy.isfinite(ratio).all()):
+        return None                                            # (C prints a NaN's sign, Python does not)
+    mlp, apps, rank, crk, ratio = (numpy.ascontiguousarray(x) for x in (mlp, apps, rank, crk, ratio))
+    out = numpy.empty(len(blob) + 120 * n, dtype=numpy.uint8)           # (not zero-filled)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    size = nv.check(nv.lib.mc_format_gc(blob, len(blob), n, vp(mlp), vp(apps), vp(rank), vp(crk), vp(ratio),
+                                        vp(out), out.size))
+    return str(memoryview(out)[:size], "utf-8")

@@ -11,6 +11,8 @@ a fallback of the engine.
 """
 import abc
 import collections.abc
+import contextlib
+import gc
 import random
 from math import log2
 from typing import Dict, List, TextIO, Tuple, Union
@@ -19,6 +21,20 @@ import numpy as np
 import torch
 
 from .FileLib import wc_l
+
+
+@contextlib.contextmanager
+def gc_paused():
+    """Building 10^6 result tuples triggers the cycle collector again and again, each time walking every
+    object built so far (measured: 0.65 -> 0.50 s for the columns of ml2p_iter2gc, 3x with zip(*rows));
+    none of these rows can form a cycle."""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class SampleKeys(collections.abc.Sequence):
@@ -201,7 +217,8 @@ class MonteCarlo(metaclass=abc.ABCMeta):
                 order = np.argsort(np.asarray(ml2p, dtype=np.float64), kind="stable").tolist()
                 first = parts if using_component else pwds
                 count = lines.count.tolist()
-                return [(first[i], count[i], ml2p[i]) for i in order]
+                with gc_paused():
+                    return [(first[i], count[i], ml2p[i]) for i in order]
         wc_l(testing_set)                                   # rewinds, as the reference does
         counts: Dict[str, int] = {}
         for line in testing_set:

@@ -16,6 +16,11 @@ def lap(name):
 train = synth.zipf_corpus(100000); test = synth.zipf_corpus(T, oov_frac=0.01, stream=1); lap("synthetic corpora")
 m = BackWordsMonteCarlo(synth.as_file(train), splitter="", threshold=10); lap("train + compile table")
 m._dev; lap("upload")
+if len(sys.argv) > 3 and sys.argv[3] == "unique":
+    # a test set of T DISTINCT passwords (the model's own most probable strings): the host glue at its worst
+    ml2p_, lens_, syms_ = m._dev.enumerate(28.0, 4, 256)          # ~2e6 distinct strings of this model
+    test = m._flat.decode(syms_[:T], lens_[:T])
+    lap(f"unique test set ({len(test)} distinct strings)")
 keys = m.sample(N); lap(f"sample({N})")
 mc = MonteCarloLib(keys); lap("MonteCarloLib(keys)")
 fd = synth.as_file(test); lap("test file object")

@@ -292,6 +292,34 @@ def test_parse_file_native_ingest_equals_line_loop(big_model):
     assert comp_fast == comp_loop
 
 
+def test_gc_columns_and_native_write2(big_model):
+    """ml2p_iter2gc's vectorised columns == the reference's running loop (lib4mc/MonteCarloLib.py:47-58), and
+    write2 through mc_format_gc == its f-string lines (:65-68), on 2e4 distinct test passwords; a list the
+    caller changed before write2 is written as changed."""
+    m, _ = big_model
+    m.seed(5)
+    mc = MonteCarloLib(m.sample(200000))
+    test = synth.zipf_corpus(60000, oov_frac=0.02, stream=7)
+    scored = m.parse_file(synth.as_file(test))
+    assert len(scored) > 5000
+    gc = mc.ml2p_iter2gc(scored)
+    total, run, prev = sum(c for _, c, _ in scored), 0, 0
+    for (pwd, x, cnt, rank, cracked, ratio), (wp, wc, wx) in zip(gc, scored):
+        run += wc
+        assert (pwd, x, cnt, cracked, ratio) == (wp, wx, wc, run, run / total * 100)
+        assert rank > prev
+        prev = rank
+    want = "".join(f"{p}\t{x:.8f}\t{c}\t{r}\t{k}\t{q:5.2f}\n" for p, x, c, r, k, q in gc)
+    buf = io.StringIO()
+    mc.write2(buf)
+    assert buf.getvalue() == want
+    gc = mc.ml2p_iter2gc(scored)
+    gc[0] = ("changed", 1.0, 2, 3, 4, 5.0)
+    buf = io.StringIO()
+    mc.write2(buf)
+    assert buf.getvalue().split("\n")[0] == "changed\t1.00000000\t2\t3\t4\t 5.00"
+
+
 def test_scoring_matches_c_oracle(big_model):
     m, cm = big_model
     test = list(dict.fromkeys(synth.zipf_corpus(30000, oov_frac=0.02, stream=1))) + ["", "a" * 300]

@@ -389,3 +389,28 @@ def test_enumeration_walk_over_compiled_table(case, train_char, train_tab):
     digits = 5 if backoff else 8
     text = "".join("%s\t%.*f\n" % ("".join(flat.symbols[s] for s in syms), digits, x) for syms, x in found)
     check_enum_text(fx, text)
+
+
+def test_native_write2_formatting_equals_fstrings():
+    """mc_format_gc == the f-string loop of write2 (reference lib4mc/MonteCarloLib.py:65-68) byte for byte:
+    rounding ties of %.8f / %5.2f, wide integers, non-ASCII passwords; rows it does not take (components
+    lists, guess numbers beyond int64, a newline inside a password, NaN) leave it to the loop."""
+    from montecarlo_amd.lib4mc.MonteCarloLib import _format_native
+    rng = np.random.default_rng(11)
+    n = 5000
+    pw = synth.zipf_corpus(n - 6, vocab=2000) + ["", "pässwörd", "密码123", "tab\tinside", "\U0001F600", " x "]
+    mlp = (rng.random(n) * 80).tolist()
+    mlp[:12] = [0.0, -0.0, 0.5, 1.5, 2.675, 1e-9, 5e-9, 0.123456785, 0.123456775, 1022.0, 1e15, 33.000000005]
+    apps = rng.integers(1, 10 ** 6, size=n).tolist()
+    rank = [int(x) for x in np.cumsum(rng.integers(1, 10 ** 12, size=n))]
+    rank[-1] = 2 ** 63 - 1
+    crk = np.cumsum(apps).tolist()
+    ratio = [c / crk[-1] * 100 for c in crk]
+    ratio[:4] = [0.005, 0.015, 99.995, 100.0]
+    gc = list(zip(pw, mlp, apps, rank, crk, ratio))
+    want = "".join(f"{p}\t{m:.8f}\t{a}\t{r}\t{c}\t{q:5.2f}\n" for p, m, a, r, c, q in gc)
+    assert _format_native(gc) == want
+    assert _format_native(gc[:100]) is None                                     # small: not worth the call
+    for bad in ((["a", "b"], 1.0, 1, 1, 1, 1.0), ("x", 1.0, 1, 2 ** 63, 1, 1.0), ("x\ny", 1.0, 1, 1, 1, 1.0),
+                ("x", float("nan"), 1, 1, 1, 1.0), ("\ud800", 1.0, 1, 1, 1, 1.0)):
+        assert _format_native(gc[:600] + [bad]) is None

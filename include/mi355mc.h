@@ -213,6 +213,11 @@ int mc_train_nwords(const char *utf8, size_t bytes, uint32_t n, uint32_t splitte
                     uint32_t skip4word, uint32_t start_cp, uint32_t end_cp, mc_trained **out);
 int mc_train_backwords(const char *utf8, size_t bytes, uint32_t splitter_cp, uint32_t start4word, uint32_t skip4word,
                        uint32_t threshold, uint32_t max_gram, uint32_t start_cp, uint32_t end_cp, mc_trained **out);
+/* nwords_counter of the v2 model (nwords_v2/nwords_trainer_v2.py:12-56): lines "pwd\tseg\ttag\tseg\ttag...",
+ * contexts = the last n-1 CHARACTERS, transitions = pieces seen at least `threshold` times, else their
+ * characters.  MC_TRAINED_CTX_UNITS of such a model holds code points (not symbol ids); it compiles as
+ * MC_KIND_V2 only.  A line whose segments do not rebuild the password is MC_ERR_ARG ("error1" in the reference). */
+int mc_train_v2(const char *utf8, size_t bytes, uint32_t n, uint32_t end_cp, uint32_t threshold, mc_trained **out);
 void mc_trained_free(mc_trained *t);
 enum {
     MC_TRAINED_CTX_OFF = 0,      /* uint32[n_ctx+1] */

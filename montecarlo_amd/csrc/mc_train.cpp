@@ -260,6 +260,7 @@ struct mc_trained {
     std::vector<uint64_t> row_off, word_cnt;
     std::vector<double> ent_prob, ent_cum, ent_ml2p;
     uint32_t start_sym, end_sym, n_lead;
+    bool v2 = false;  // contexts are code points, not symbol ids (mc_train_v2)
 };
 
 namespace {
@@ -330,6 +331,123 @@ extern "C" int mc_train_nwords(const char *utf8, size_t bytes, uint32_t n, uint3
         rows.push_back(std::move(pr));
     }
     *out = finish(c, rows, n - 1);
+    return MC_OK;
+}
+
+// nwords_counter of the v2 model (nwords_v2/nwords_trainer_v2.py:12-56): a line is
+// "pwd\tseg\ttag\tseg\ttag..."; the segments' LENGTHS cut pwd + end into pieces (:21-31), pieces seen fewer
+// than `threshold` times are spelled out character by character (:38-43), the context of a transition is
+// the last n-1 CHARACTERS written so far (:44-47).  Contexts are kept as code points, transitions as
+// interned texts; dict orders are the reference's (first-seen).
+extern "C" int mc_train_v2(const char *utf8, size_t bytes, uint32_t n, uint32_t end_cp, uint32_t threshold,
+                           mc_trained **out) {
+    if (!out || (bytes && !utf8) || n < 2) {
+        mc_set_error("mc_train_v2: bad argument (n must be at least 2)");
+        return MC_ERR_ARG;
+    }
+    *out = nullptr;
+    Corpus c;
+    c.end_sym = c.syms.get(Seq{end_cp});
+    c.start_sym = MC_NONE;
+    std::unordered_map<Seq, uint32_t, SeqHash> seen;  // tuple of piece ids -> index in c.uniq
+    Seq line, pieces, piece;
+    std::vector<uint32_t> seg_len;
+    size_t at = 0;
+    while (at < bytes) {
+        size_t nl = at;
+        while (nl < bytes && utf8[nl] != '\n') ++nl;
+        size_t a = at, b = nl;
+        at = nl + 1;
+        while (a < b && (utf8[a] == '\r' || utf8[a] == '\n')) ++a;
+        while (b > a && (utf8[b - 1] == '\r' || utf8[b - 1] == '\n')) --b;
+        if (!decode_utf8(utf8 + a, b - a, line)) {
+            mc_set_error("trainer: the training text is not valid UTF-8");
+            return MC_ERR_ARG;
+        }
+        // fields between tabs: field 0 is the password, the odd fields are its segments
+        seg_len.clear();
+        size_t pwd_len = line.size(), field = 0, start = 0;
+        for (size_t i = 0; i <= line.size(); ++i)
+            if (i == line.size() || line[i] == '\t') {
+                if (field == 0) pwd_len = i;
+                else if (field % 2 == 1) seg_len.push_back((uint32_t)(i - start));
+                ++field;
+                start = i + 1;
+            }
+        seg_len.push_back(1);  // raw_sections.append(end_chr)
+        line.resize(pwd_len);
+        line.push_back(end_cp);
+        pieces.clear();
+        size_t cut = 0, covered = 0;
+        for (uint32_t len : seg_len) {
+            const size_t lo = std::min(cut, line.size()), hi = std::min(cut + len, line.size());  // (slices clamp)
+            piece.assign(line.begin() + lo, line.begin() + hi);
+            cut += len;
+            covered += piece.size();
+            const uint32_t id = c.syms.get(piece);
+            pieces.push_back(id);
+            auto it = c.word_pos.find(id);
+            if (it == c.word_pos.end()) {
+                c.word_pos.emplace(id, (uint32_t)c.word_sym.size());
+                c.word_sym.push_back(id);
+                c.word_cnt.push_back(1);
+            } else {
+                ++c.word_cnt[it->second];
+            }
+        }
+        // "".join(sections) != pwd: the slices are consecutive from 0 and clamp at the end of pwd, so they
+        // rebuild it exactly when they reach its end (segments that run past it leave empty pieces, which
+        // the reference accepts)
+        if (covered != line.size() || line.size() < 4) {
+            mc_set_error("error1 (nwords_trainer_v2.py:32-33: the segments do not rebuild the password, or it is "
+                         "shorter than 3 characters)");
+            return MC_ERR_ARG;
+        }
+        auto it = seen.find(pieces);
+        if (it == seen.end()) {
+            seen.emplace(pieces, (uint32_t)c.uniq.size());
+            c.uniq.push_back(pieces);
+            c.mult.push_back(1);
+        } else {
+            ++c.mult[it->second];
+        }
+    }
+    const uint32_t reach = n - 1;
+    RowTable counts;  // rows keyed by the context's code points
+    Seq ctx, toks;
+    for (size_t u = 0; u < c.uniq.size(); ++u) {
+        toks.clear();
+        for (uint32_t id : c.uniq[u]) {
+            if (c.word_cnt[c.word_pos[id]] >= threshold) {
+                toks.push_back(id);
+            } else {
+                const Seq text = c.syms.text[id];  // (a copy: get() below may grow the table)
+                for (uint32_t cp : text) toks.push_back(c.syms.get(Seq{cp}));
+            }
+        }
+        ctx.clear();
+        for (uint32_t tok : toks) {
+            const uint32_t r = counts.row_of(ctx.data(), (uint32_t)ctx.size());
+            counts.add(r, tok, c.mult[u]);
+            const Seq &text = c.syms.text[tok];
+            ctx.insert(ctx.end(), text.begin(), text.end());
+            if (ctx.size() > reach) ctx.erase(ctx.begin(), ctx.end() - reach);
+        }
+    }
+    std::vector<ProbRow> rows;
+    rows.reserve(counts.rows.size());
+    for (const Row &r : counts.rows) {
+        uint64_t total = 0;
+        for (uint64_t v : r.cnt) total += v;
+        ProbRow pr;
+        pr.ctx = r.ctx;
+        pr.sym = r.sym;
+        for (uint64_t v : r.cnt) pr.p.push_back((double)v / (double)total);
+        rows.push_back(std::move(pr));
+    }
+    mc_trained *t = finish(c, rows, 0);
+    t->v2 = true;
+    *out = t;
     return MC_OK;
 }
 
@@ -734,7 +852,7 @@ extern "C" int64_t mc_trained_array(const mc_trained *t, int what, void *dst, si
 // The trained rows as the descriptor mc_table_compile takes (n-gram / backoff kinds).
 extern "C" int mc_trained_compile(const mc_trained *t, uint32_t kind, uint32_t order, uint32_t min_len,
                                   uint32_t max_len, uint32_t flags, uint32_t guide_factor, mc_table **out) {
-    if (!t || !out || (kind != MC_KIND_NGRAM && kind != MC_KIND_BACKOFF)) {
+    if (!t || !out || (kind != MC_KIND_NGRAM && kind != MC_KIND_BACKOFF && kind != MC_KIND_V2)) {
         mc_set_error("mc_trained_compile: bad argument");
         return MC_ERR_ARG;
     }
@@ -763,5 +881,17 @@ extern "C" int mc_trained_compile(const mc_trained *t, uint32_t kind, uint32_t o
     d.guide_factor = guide_factor;
     d.sym_text_off = t->sym_text_off.data();
     d.sym_text = t->sym_text.data();
+    if (t->v2) {
+        // contexts are characters: a symbol's units are the code points of its text
+        if (kind != MC_KIND_V2) {
+            mc_set_error("mc_trained_compile: a model trained by mc_train_v2 compiles as MC_KIND_V2 only");
+            return MC_ERR_ARG;
+        }
+        d.sym_unit_off = t->sym_text_off.data();
+        d.sym_units = t->sym_text.data();
+    } else if (kind == MC_KIND_V2) {
+        mc_set_error("mc_trained_compile: MC_KIND_V2 needs a model trained by mc_train_v2");
+        return MC_ERR_ARG;
+    }
     return mc_table_compile(&d, out);
 }

@@ -47,8 +47,9 @@ def read_text(source) -> str:
 
 
 class Trained:
-    def __init__(self, handle):
+    def __init__(self, handle, v2: bool = False):
         self._h = handle
+        self.v2 = v2                 # mc_train_v2: contexts are strings of characters (code points)
         off = self.array(nv.TRAINED_SYM_TEXT_OFF)
         text = self.array(nv.TRAINED_SYM_TEXT).astype("<u4").tobytes().decode("utf-32-le", "surrogatepass")
         self.symbols: List[str] = [text[a:b] for a, b in zip(off[:-1].tolist(), off[1:].tolist())]
@@ -82,7 +83,10 @@ class Trained:
             cum = self.array(nv.TRAINED_ENT_CUM)
             table = {}
             for r in range(len(ctx_off) - 1):
-                ctx = tuple(sym[u] for u in units[ctx_off[r]:ctx_off[r + 1]])
+                if self.v2:
+                    ctx = "".join(map(chr, units[ctx_off[r]:ctx_off[r + 1]]))
+                else:
+                    ctx = tuple(sym[u] for u in units[ctx_off[r]:ctx_off[r + 1]])
                 a, b = row_off[r], row_off[r + 1]
                 keys = [sym[s] for s in ent_sym[a:b]]
                 table[ctx] = (dict(zip(keys, prob[a:b])), keys, cum[a:b].copy())

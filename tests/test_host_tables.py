@@ -136,10 +136,29 @@ def test_secondary(train_char):
 
 
 def test_v2(train_v2):
+    """The native v2 trainer (mc_train_v2) and the dict-based one build the reference's table (golden digest of
+    rows in dict order, fp64 as hex) and the reference's `words`; the compiled walk reproduces its samples."""
+    from montecarlo_amd.lib4mc.ProbLib import expand_2d
+    from montecarlo_amd.nwords_v2.nwords_trainer_v2 import nwords_counter as v2_counter
     fx = golden("v2_n4.json")
     m = NWords2MonteCarlo(synth.as_file(train_v2), 4)
+    assert hasattr(m, "_trained")
     check_table(fx, m)
     check_walk(fx, m, keep_len=True)
+    probs, words = v2_counter(synth.as_file(train_v2), 4, "\x03")
+    assert rows_of(expand_2d(probs)) == rows_of(m.nwords)
+    assert list(words.items()) == list(m.words.items())
+    # other orders, a larger synthetic corpus, segments that run past the password (accepted by the reference:
+    # its slices clamp), and the reference's "error1" when they fall short
+    for n, lines in ((6, synth.v2_corpus(3000)), (3, train_v2[:500] + ["abcdef\tabc\tL\tdefgh\tL"])):
+        nat = NWords2MonteCarlo(synth.as_file(lines), n)
+        probs, words = v2_counter(synth.as_file(lines), n, "\x03")
+        assert rows_of(expand_2d(probs)) == rows_of(nat.nwords)
+        assert list(words.items()) == list(nat.words.items())
+    with pytest.raises(nv.NativeError, match="error1"):
+        NWords2MonteCarlo(synth.as_file(["abcdef\tabc\tL\tde\tL"]), 4)
+    with pytest.raises(Exception, match="error1"):
+        v2_counter(synth.as_file(["abcdef\tabc\tL\tde\tL"]), 4, "\x03")
 
 
 def test_bpe():

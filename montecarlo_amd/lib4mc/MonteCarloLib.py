@@ -155,3 +155,22 @@ def _format_native(gc, cols=None) -> "str | None":
     size = nv.check(nv.lib.mc_format_gc(blob, len(blob), n, vp(mlp), vp(apps), vp(rank), vp(crk), vp(ratio),
                                         vp(out), out.size))
     return str(memoryview(out)[:size], "utf-8")
+
+
+def _monotone_ranks(est: numpy.ndarray, cnt: numpy.ndarray, add1: bool) -> List[int]:
+    """rank_i = ceil(max(est_i, rank_{i-1} + add)), rank_0 = 0 (reference :47-55).
+    While every value is below 2^52 (float and int comparisons exact) this is a running
+    maximum; beyond that it is evaluated with the reference's own expression, whose
+    numpy-float-vs-int comparisons are themselves lossy there."""
+    if est.size and numpy.all(numpy.isfinite(est)) and float(est.max()) < 2.0 ** 52:
+        c = numpy.ceil(est).astype(numpy.int64)
+        if add1:
+            i = numpy.arange(1, c.size + 1, dtype=numpy.int64)
+            s = numpy.maximum.accumulate(numpy.maximum(c - i, 0))
+            return (s + i).tolist()
+        return numpy.maximum.accumulate(numpy.maximum(c, 0)).tolist()
+    out, prev, step = [], 0, 1 if add1 else 0
+    for e, k in zip(est, cnt):
+        prev = ceil(max(e if k > 0 else 1, prev + step))
+        out.append(prev)
+    return out

@@ -433,3 +433,22 @@ def test_native_write2_formatting_equals_fstrings():
     for bad in ((["a", "b"], 1.0, 1, 1, 1, 1.0), ("x", 1.0, 1, 2 ** 63, 1, 1.0), ("x\ny", 1.0, 1, 1, 1, 1.0),
                 ("x", float("nan"), 1, 1, 1, 1.0), ("\ud800", 1.0, 1, 1, 1, 1.0)):
         assert _format_native(gc[:600] + [bad]) is None
+
+
+def test_monotone_ranks_equal_reference_loop():
+    """_monotone_ranks (vectorised) == the reference's running expression (lib4mc/MonteCarloLib.py:47-55),
+    including estimates beyond 2^52 where it falls back to that expression itself."""
+    from math import ceil
+    from montecarlo_amd.lib4mc.MonteCarloLib import _monotone_ranks
+    rng = np.random.default_rng(3)
+    for scale in (1e3, 1e9, 2.0 ** 70):
+        est = np.sort(rng.random(3000)) * scale
+        est[:5] = [1.0, 1.0, 1.0, 2.0, 2.5]
+        cnt = (rng.random(3000) > 0.05).astype(np.int64)
+        est = np.where(cnt > 0, est, 1.0)
+        for add1 in (True, False):
+            want, prev = [], 0
+            for e in est:
+                prev = ceil(max(e, prev + (1 if add1 else 0)))
+                want.append(prev)
+            assert _monotone_ranks(est, cnt, add1) == want

@@ -4,9 +4,9 @@
 guess-number hot path on one GPU:
 
     sample N=1e7 strings (k_sample) -> radix sort + prefix sum of 1/(n p) (mc_rank_build)
-    || score T=1e6 test passwords (k_score, second stream: independent of the samples)
-    -> bisect them into the curve (k_query)
-    [-> all-reduce of the per-test partial sums when world_size > 1]
+    -> score T=1e6 test passwords (k_score) -> bisect them into the curve (k_query)
+    [-> all-reduce of the per-test partial sums when world_size > 1, on its own stream beside the
+        next step's sampling]
 
 Inputs (compiled tables, encoded test set) are resident in HBM before the timed region.
 Prints ONE JSON line on rank 0.  `python bench.py --gpus N --steps K --warmup W`; for N > 1
@@ -23,9 +23,10 @@ import time
 import numpy as np
 import torch
 
-if "--rehearse-on-one-gpu" in sys.argv:
-    # ranks sharing one GPU: the sort takes its tiles by ticket (csrc/mc_rank.hip: a fixed assignment needs the
-    # whole grid resident, which two processes on one GPU deny each other); read once when the library loads
+if "--rehearse-on-one-gpu" in sys.argv or "--overlap-score" in sys.argv:
+    # something else runs on the GPU while the sort does (another rank's process, the scoring kernel on a
+    # second stream): the sort takes its tiles by ticket (csrc/mc_rank.hip: the default fixed assignment needs
+    # its whole grid resident, i.e. the GPU to itself); read once when the library loads
     os.environ.setdefault("MC_SORT_TICKETS", "1")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -67,7 +68,10 @@ def main():
     ap.add_argument("--tests", type=int, default=1_000_000)
     ap.add_argument("--train-lines", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--serial", action="store_true", help="score on the main stream instead of overlapping it")
+    ap.add_argument("--overlap-score", action="store_true",
+                    help="score the test set on a second stream beside the rank build (the sort then takes its "
+                         "tiles by ticket; slower than the default since the sort got faster on its own)")
+    ap.add_argument("--serial", action="store_true", help=argparse.SUPPRESS)        # (the default now)
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="rehearsal of the multi-rank control flow on a 1-GPU box: every rank uses cuda:0 and the "
                          "collective runs over gloo (the printed numbers mean nothing)")
@@ -109,7 +113,8 @@ def main():
     ws = torch.empty(nv.lib.mc_rank_workspace_bytes(N), dtype=torch.uint8, device=dev)
     t_ml2p = torch.empty(T, dtype=torch.float64, device=dev)
     # two result buffers and a stream of its own for the collective: a step's all-reduce runs beside the
-    # next step's sampling (world > 1); the main stream only waits for it when the buffer comes round again
+    # next step's SAMPLING (world > 1); the main stream waits for it before the next rank build, whose
+    # persistent sort wants the GPU to itself
     q_pos = [torch.empty(T, dtype=torch.float64, device=dev) for _ in range(2)]
     reduced = [None, None]
     comm = torch.cuda.Stream(device=dev) if world > 1 else None
@@ -117,24 +122,25 @@ def main():
     seed = 20250304
 
     ev = {k: [] for k in ("sample", "rank", "score", "query")}
-    side = None if args.serial else torch.cuda.Stream(device=dev)
+    side = torch.cuda.Stream(device=dev) if args.overlap_score else None
     main_stream = torch.cuda.current_stream(dev)
 
     def step(it: int, timed: bool):
-        """sample -> rank build on the main stream; the test set is scored on a second stream while
-        the rank build runs (it does not depend on the samples); the queries join the two."""
+        """sample -> rank build -> score -> queries on the main stream (--overlap-score: the test set is
+        scored on a second stream beside the rank build; it does not depend on the samples)."""
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
         slot = it & 1
-        if reduced[slot] is not None:
-            main_stream.wait_event(reduced[slot])           # this buffer's all-reduce of two steps ago
-            reduced[slot] = None
         first = (it * world + rank) * N                     # disjoint Philox sample ids per rank and step
         marks[0].record()
         dm.sample(N, seed, first_id=first, out=keys)
         marks[1].record()
+        for i, done in enumerate(reduced):                  # the previous step's all-reduce ran beside k_sample
+            if done is not None:
+                main_stream.wait_event(done)
+                reduced[i] = None
         if side is not None:
-            # beside the rank build (streaming kernels that leave the gather path idle), not beside
-            # k_sample (both are gather-bound: measured, they only slow each other down)
+            # beside the rank build, not beside k_sample (both are gather-bound: measured, they only slow
+            # each other down)
             side.wait_event(marks[1])
             with torch.cuda.stream(side):
                 marks[3].record()

@@ -364,7 +364,14 @@ int mc_score_bpe(mc_model *m, const uint32_t *cps, const uint8_t *cls, const uin
 /* ---- rank estimation: MonteCarloLib.__init__ (lib4mc/MonteCarloLib.py:10-28): sort the
  * sampled -log2 p ascending, positions = cumsum(2^(key - log2 n_global)).  keys_sorted and
  * positions are outputs [n]; keys_in is left untouched.  n_global = total samples over all
- * GPUs (= n on one GPU): each shard weights with the global n so that per-shard results add. */
+ * GPUs (= n on one GPU): each shard weights with the global n so that per-shard results add.  *
+ * The sort's persistent grid is sized to what the GPU holds at once and assigns tiles by workgroup index:
+ * it wants the GPU to itself while it runs (about 0.5 ms per 1e7 keys).  A kernel that holds part of the GPU
+ * at the same time (another stream, another process) can leave it with workgroups that cannot start; the
+ * build then stalls until its spin bound and returns NaN positions.  Set MC_SORT_TICKETS=1 in the
+ * environment (read once, before the first build) where that cannot be ruled out: tiles are then taken from a
+ * counter, which is safe under any residency and ~17 % slower.
+ */
 size_t mc_rank_workspace_bytes(uint64_t n);
 int mc_rank_build(const double *keys_in, uint64_t n, uint64_t n_global, double *keys_sorted, double *positions,
                   void *workspace, size_t workspace_bytes, void *stream);

@@ -204,13 +204,13 @@ k_onesweep(const Plan *__restrict__ plan, int pass, const u64 *in, u64 *a, u64 *
     __shared__ u32 tile_off[256];  // exclusive scan of the tile's digit counts
     __shared__ u32 wave_sum[4];
     __shared__ u32 wave_below[4];
-    __shared__ u32 ticket_s[2];
+    __shared__ u32 ticket_s[1];
     u32 *ticket = err - 8 + pass;  // (TICKETS) the pass's counter among the spare words before the error word
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     // each wave owns 64 * ITEMS consecutive keys of the tile: order = (wave, round, lane).  The 256
     // digits belong to the first 256 lanes (waves 0..3).
     u64 key[ITEMS], nkey[PREFETCH ? ITEMS : 1];
     auto load_tile = [&](u32 tile, u64 *k) {
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
         const u64 t0 = (u64)tile * TILE;
         const u32 tile_n = tile < tiles ? (u32)min((u64)TILE, n - t0) : 0u;
 #pragma unroll
@@ -221,16 +221,19 @@ k_onesweep(const Plan *__restrict__ plan, int pass, const u64 *in, u64 *a, u64 *
     };
     u32 tile = blockIdx.x, tile1 = blockIdx.x + gridDim.x, ahead = 0;
     if (TICKETS) {
-        if (tid == 0) {
-            ticket_s[0] = atomicAdd(ticket, 1u);
-            ticket_s[1] = atomicAdd(ticket, 1u);
-        }
+        if (threadIdx.x == 0) ticket_s[0] = atomicAdd(ticket, 1u);
         __syncthreads();
-        tile = ticket_s[0];
-        tile1 = ticket_s[1];
+        tile = tile1 = ticket_s[0];  // (tile1 only matters to the prefetching forms, which take no tickets)
     }
     if (PREFETCH) load_tile(tile, nkey);
     while (tile < tiles) {
+    // the lane's identity is made opaque once per tile: what the compiler derives from it (shuffle lane
+    // indices, lane masks, LDS addresses) is then recomputed per tile instead of being hoisted out of
+    // the persistent loop and held in ~80 VGPRs for the whole kernel (256 x 24 needed > 256 VGPRs
+    // against 175 for the same code without the loop, which is what held it at two waves per SIMD)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wid = tid >> 6;
     for (int i = tid; i < NW * 256; i += THREADS) (&wcnt[0][0])[i] = 0;
     __syncthreads();  // (also: every wave has left the previous tile's write-out and read ticket_s)
     const u64 t0 = (u64)tile * TILE;
@@ -264,7 +267,10 @@ k_onesweep(const Plan *__restrict__ plan, int pass, const u64 *in, u64 *a, u64 *
         old = __shfl(old, leader < 0 ? 0 : leader);
         rank[r] = old + before;
     }
-    if (TICKETS && tid == 0) ahead = atomicAdd(ticket, 1u);  // the tile after next; read at the end of this one
+    // the next tile, read at the end of this one; drawn by the LAST wave, which has no look-back to
+    // run: when every workgroup of a round asks at once the answer takes microseconds (same-address
+    // atomics queue at ~11 ns each), and in wave 0 the look-back's loads would wait behind it
+    if (TICKETS && tid == THREADS - 1) ahead = atomicAdd(ticket, 1u);
     // the next tile's keys travel while this tile waits for its predecessors and writes out
     if (PREFETCH == 1) load_tile(tile1, nkey);
     __syncthreads();
@@ -335,7 +341,13 @@ k_onesweep(const Plan *__restrict__ plan, int pass, const u64 *in, u64 *a, u64 *
                         atomicOr(err, 1u);
                         done = true;
                     }
-                    __builtin_amdgcn_s_sleep(1);
+                    // back off: a tile that has waited long is waiting for a workgroup that cannot start (a
+                    // co-tenant holds its place) and polling flat out -- 10^5 lanes of uncached loads --
+                    // starves the very kernel that has to finish first (seen: seconds instead of
+                    // microseconds beside k_score)
+                    if (spins < 32) __builtin_amdgcn_s_sleep(1);
+                    else if (spins < 256) __builtin_amdgcn_s_sleep(16);
+                    else __builtin_amdgcn_s_sleep(127);
                 }
             }
             __hip_atomic_store(mine, (excl + tot) | LB_INCL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -354,7 +366,7 @@ k_onesweep(const Plan *__restrict__ plan, int pass, const u64 *in, u64 *a, u64 *
             if (at < (u32)TILE) stage[at] = key[r]; else atomicOr(err, 2u);
         }
     }
-    if (TICKETS && tid == 0) ticket_s[0] = ahead;
+    if (TICKETS && tid == THREADS - 1) ticket_s[0] = ahead;
     __syncthreads();
     // digit-contiguous runs out to global
     for (u32 j = tid; j < tile_n; j += THREADS) {
@@ -365,8 +377,12 @@ k_onesweep(const Plan *__restrict__ plan, int pass, const u64 *in, u64 *a, u64 *
         const u64 at = base[d] + (j - tile_off[d]);
         if (at < n) dst[at] = k; else atomicOr(err, 2u);
     }
-    tile = tile1;
-    tile1 = TICKETS ? ticket_s[0] : tile1 + gridDim.x;
+    if (TICKETS) {
+        tile = tile1 = ticket_s[0];
+    } else {
+        tile = tile1;
+        tile1 += gridDim.x;
+    }
     }  // next tile of this workgroup
 }
 
@@ -494,29 +510,33 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // The onesweep variant in use: workgroup shape (threads x keys per lane = tile) and where the next
 // tile's keys are requested (0: at the top of its own iteration, 1: before the look-back, 2: after
-// it).  Tuning knobs (MC_SORT_VARIANT, MC_SORT_PREFETCH, read once); results never depend on them.
+// it).  MC_SORT_VARIANT (1: 256 x 24) / MC_SORT_TICKETS are read once; results never depend on them.  Only shapes
+// that (a) compile without register spills and (b) fill the SIMDs evenly are offered: the fixed tile
+// assignment needs the occupancy the API reports to be the occupancy the hardware gives, and a
+// workgroup of 6 waves at 3 waves per SIMD (384 x 16) is reported as two per CU but placed as one --
+// half the grid then never starts and the other half spins to the bound.
 typedef void (*onesweep_fn)(const Plan *, int, const u64 *, u64 *, u64 *, u64, u32, const u32 *, u32 *, u64 *);
 struct SortVariant {
     onesweep_fn fn;
     int threads, items, prefetch;
 };
 template <int T, int I, int W>
-SortVariant onesweep_pick(int prefetch) {
-    onesweep_fn f = prefetch == 1 ? k_onesweep<T, I, 1, W> : prefetch == 2 ? k_onesweep<T, I, 2, W> : k_onesweep<T, I, 0, W>;
-    return SortVariant{f, T, I, prefetch};
+SortVariant onesweep_pick() {
+    // (the prefetching forms of the kernel -- PREFETCH 1 and 2 -- are kept in the source for the next
+    // compiler: with this one they spill or gain nothing, and none is instantiated)
+    return SortVariant{k_onesweep<T, I, 0, W>, T, I, 0};
 }
 const SortVariant &sort_variant() {
     static const SortVariant v = [] {
         const int tickets = getenv("MC_SORT_TICKETS") ? atoi(getenv("MC_SORT_TICKETS")) : 0;
         const int which = tickets ? 8 : getenv("MC_SORT_VARIANT") ? atoi(getenv("MC_SORT_VARIANT")) : 0;
-        int pf = getenv("MC_SORT_PREFETCH") ? atoi(getenv("MC_SORT_PREFETCH")) : 0;
-        pf = pf >= 0 && pf <= 2 ? pf : 0;
-        // (every variant here compiles without register spills: the ones that needed scratch memory
-        // were slower, and the one run of such a kernel beside k_score on a second queue faulted)
+        // (spill-free shapes only: the ones that needed scratch memory were slower, and the one run of such a
+        // kernel beside k_score on a second queue faulted.  512 x 12 at 4 waves per SIMD: 0.553 ms per
+        // build of 1e7 keys against 0.609 ms for 256 x 24 at 2; both with prefetch lose or spill)
         switch (which) {
-        case 7: return onesweep_pick<384, 16, 2>(pf);   // 6144 keys, 6 waves
-        case 8: return SortVariant{k_onesweep<256, 24, 0, 2, true>, 256, 24, 0};  // tiles by ticket (shared GPU)
-        default: return onesweep_pick<256, 24, 2>(0);   // 6144 keys, 4 waves; 2 workgroups per CU (its prefetching forms spill)
+        case 1: return onesweep_pick<256, 24, 2>();    // 6144 keys, 4 waves x 252 VGPRs, two workgroups per CU
+        case 8: return SortVariant{k_onesweep<512, 12, 0, 4, true>, 512, 12, 0};  // tiles by ticket (shared GPU)
+        default: return onesweep_pick<512, 12, 4>();   // 6144 keys, 8 waves x 128 VGPRs, two workgroups per CU
         }
     }();
     return v;

@@ -31,7 +31,7 @@ variants = sys.argv[1].split(",") if len(sys.argv) > 1 else ["0"]
 prefetch = sys.argv[2].split(",") if len(sys.argv) > 2 else ["0"]
 for v in variants:
     for pf in prefetch:
-        env = dict(os.environ, MC_SORT_VARIANT=v, MC_SORT_PREFETCH=pf)
+        env = dict(os.environ, MC_SORT_VARIANT=v)
         r = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, timeout=300, env=env)
         print(f"variant={v} prefetch={pf} rc={r.returncode} {r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-1500:]}", flush=True)
         if r.returncode != 0:

@@ -364,7 +364,8 @@ int mc_score_bpe(mc_model *m, const uint32_t *cps, const uint8_t *cls, const uin
 /* ---- rank estimation: MonteCarloLib.__init__ (lib4mc/MonteCarloLib.py:10-28): sort the
  * sampled -log2 p ascending, positions = cumsum(2^(key - log2 n_global)).  keys_sorted and
  * positions are outputs [n]; keys_in is left untouched.  n_global = total samples over all
- * GPUs (= n on one GPU): each shard weights with the global n so that per-shard results add.  *
+ * GPUs (= n on one GPU): each shard weights with the global n so that per-shard results add.
+ *
  * The sort's persistent grid is sized to what the GPU holds at once and assigns tiles by workgroup index:
  * it wants the GPU to itself while it runs (about 0.5 ms per 1e7 keys).  A kernel that holds part of the GPU
  * at the same time (another stream, another process) can leave it with workgroups that cannot start; the

@@ -13,7 +13,7 @@
  * those precomputations.  Uniforms: Philox4x32-10 as defined in oracle/philox.py.
  *
  * Pinned by tests/test_oracle_golden.py::test_c_oracle_* against the golden vectors
- * recorded from the reference (tests/golden/*.json).
+ * recorded from the reference (the JSON files under tests/golden).
  *
  * Input layout = struct mc_model_desc of include/mi355mc.h (the flattened dict-of-dict).
  */

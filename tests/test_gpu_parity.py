@@ -517,6 +517,15 @@ def test_enumeration_at_scale_matches_oracle(big_model):
     assert bool((ml2p < thr).all())
     with pytest.raises(nv.NativeError, match="max_nodes"):
         m._dev.enumerate(thr, 4, 256, max_nodes=1000)
+    # nothing is below the threshold (the reference's iterate returns at once, :27): no strings, no error
+    for empty_thr in (0.0, -1.0, 1e-9):
+        e_ml2p, e_lens, e_syms = m._dev.enumerate(empty_thr, 4, 256)
+        assert len(e_ml2p) == len(e_lens) == len(e_syms) == 0
+    # min_len 0: a string may be empty (the end symbol straight from the start context)
+    z_ml2p, z_lens, z_syms = m._dev.enumerate(12.0, 0, 256)
+    z_want = orc.enumerate_strings(probs, 12.0, "\x00", "\x03", 0)
+    assert m._flat.decode(z_syms, z_lens) == [w[0] for w in z_want]
+    assert np.array_equal(z_ml2p.view(np.uint64), np.array([w[1] for w in z_want], dtype=np.float64).view(np.uint64))
 
 
 def golden_path(name):

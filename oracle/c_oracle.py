@@ -127,8 +127,8 @@ class COracleModel:
         self._h = C.c_void_p(lib().orc_model_new(C.byref(d)))
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_model_free(self._h)
+        if getattr(self, "_h", None) and _lib is not None:  # (module globals go first at interpreter exit)
+            _lib.orc_model_free(self._h)
             self._h = None
 
     def sample(self, count: int, seed: int, first_id: int = 0, max_draws: int = 1 << 16, stride: int = 0,

@@ -445,6 +445,35 @@ def test_rank_edge_sizes():
     assert float(((pa + pb - pf).abs() / pf.clamp(min=1e-300)).max()) < REL
 
 
+def test_rank_key_distributions():
+    """Key sets the sampler never produces but the C ABI accepts: the radix sort must not care.
+    Many tiles each; checked against torch.sort bit for bit."""
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(11)
+    n = 1_000_003
+    up = torch.arange(n, dtype=torch.float64) * 1e-4 + 3.0
+    cases = {
+        "ascending": up,
+        "descending": up.flip(0),
+        "two values": torch.where(torch.rand(n, generator=g) < 0.999, 17.25, 17.5).double(),
+        # one value holds almost every key
+        "one heavy bin": torch.where(torch.rand(n, generator=g) < 0.98, torch.tensor(40.0, dtype=torch.float64),
+                                     torch.rand(n, generator=g, dtype=torch.float64) * 200),
+        # every byte of the key varies: any positive finite double, denormals included
+        "all bit patterns": torch.randint(0, 0x7FEFFFFFFFFFFFFF, (n,), generator=g, dtype=torch.int64)
+        .view(torch.float64),
+        "runs": torch.repeat_interleave(torch.rand(n // 1000 + 1, generator=g, dtype=torch.float64) * 90, 1000)[:n],
+    }
+    for name, keys in cases.items():
+        keys = keys.contiguous().to(dev)
+        rk = DeviceRank(keys)
+        srt, _ = torch.sort(keys)
+        assert torch.equal(rk.keys_sorted.view(torch.int64), srt.view(torch.int64)), name
+        if name != "all bit patterns":                       # (there the weights overflow: 2 ** 1e308)
+            ref = torch.cumsum(torch.exp2(srt - np.log2(n)), 0)
+            assert float(((rk.positions - ref).abs() / ref).max()) < REL, name
+
+
 def test_distribution_vs_reference_sampler(train_char):
     """(d): the reference's own Mersenne-Twister samples (golden/dist_backwords_thr10.npz) against
     Philox samples from the GPU: two-sample KS on -log2 p, chi-square on string length."""

@@ -452,3 +452,43 @@ def test_monotone_ranks_equal_reference_loop():
                 prev = ceil(max(e, prev + (1 if add1 else 0)))
                 want.append(prev)
             assert _monotone_ranks(est, cnt, add1) == want
+
+
+def test_c_abi_rejects_bad_arguments_before_touching_the_device():
+    """Argument checks of the launch entry points come before any HIP call, so they can be exercised
+    on a host without a GPU: null handles / buffers, aliasing outputs, sizes beyond the documented
+    limits, a workspace that is too small.  Every rejection sets mc_last_error()."""
+    lib = nv.lib
+    buf = np.zeros(64, dtype=np.float64)
+    a, b, c = (ctypes.c_void_p(buf.ctypes.data + 8 * i) for i in (0, 16, 32))
+    big = ctypes.c_void_p(buf.ctypes.data + 8 * 48)
+
+    def rejected(rc, what):
+        assert rc < 0
+        with pytest.raises(nv.NativeError, match=what):
+            nv.check(rc)
+
+    need = lib.mc_rank_workspace_bytes(10)
+    assert need >= 10 * 8 and lib.mc_rank_workspace_bytes(10 ** 7) > lib.mc_rank_workspace_bytes(10 ** 6) > need
+    assert lib.mc_rank_build(None, 0, 0, None, None, None, 0, None) == 0            # nothing to do
+    rejected(lib.mc_rank_build(None, 10, 10, b, c, big, need, None), "mc_rank_build")
+    rejected(lib.mc_rank_build(a, 10, 9, b, c, big, need, None), "mc_rank_build")    # n_global < n
+    rejected(lib.mc_rank_build(a, 10, 10, a, c, big, need, None), "mc_rank_build")   # sorted in place
+    rejected(lib.mc_rank_build(a, 10, 10, b, b, big, need, None), "mc_rank_build")   # positions over the keys
+    rejected(lib.mc_rank_build(a, 2 ** 32, 2 ** 32, b, c, big, 1 << 62, None), "2\\^32")
+    rejected(lib.mc_rank_build(a, 10, 10, b, c, big, need - 1, None), "workspace")
+    assert lib.mc_rank_query(None, None, 0, None, 0, None, None, None) == 0
+    rejected(lib.mc_rank_query(a, b, 10, None, 5, c, None, None), "mc_rank_query")
+    rejected(lib.mc_rank_query(None, b, 10, a, 5, c, None, None), "mc_rank_query")
+    rejected(lib.mc_sample(None, 0, 10, 1, 100, a, None, None, None, 0, None), "mc_sample")
+    rejected(lib.mc_sample_injected(None, 10, a, 4, b, None, None, None, 0, None), "mc_sample_injected")
+    rejected(lib.mc_score(None, a, b, 3, c, None), "mc_score")
+    rejected(lib.mc_score_bpe(None, a, a, b, 3, c, None), "mc_score_bpe")
+    rejected(lib.mc_score_words(None, a, b, 3, 30, 10, c, None, 0, big, 64, None), "mc_score_words")
+    assert lib.mc_score_words_workspace_bytes(None, 10, 30) == 0
+    rejected(lib.mc_model_check(None, None, None), "mc_model_check")
+    # the table of the dedup must be a power of two of at least twice the rows
+    rejected(lib.mc_sample_dedup(a, a, 8, 10, 16, a, b, c, big, None), "power of two")
+    rejected(lib.mc_sample_dedup(a, a, 8, 10, 24, a, b, c, big, None), "power of two")
+    rejected(lib.mc_model_upload(None, 0, ctypes.byref(ctypes.c_void_p())), "mc_model_upload")
+    lib.mc_model_destroy(None)                                                       # a no-op, as free(NULL)

@@ -62,8 +62,8 @@ B_HIST, B_PASS, B_SCAN = 8, 16, 24
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--samples", type=int, default=10_000_000, help="samples per GPU per step")
     ap.add_argument("--tests", type=int, default=1_000_000)
     ap.add_argument("--train-lines", type=int, default=100_000)

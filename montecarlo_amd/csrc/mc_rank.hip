@@ -284,7 +284,7 @@ k_onesweep(const Plan *__restrict__ plan, int pass, const u64 *in, u64 *a, u64 *
     // the next tile's keys travel while this tile waits for its predecessors and writes out
     if (PREFETCH == 1) load_tile(tile1, nkey);
     __syncthreads();
-    u32 tot = 0, inc = 0, ginc = 0, gown = 0;
+    u32 tot = 0, inc = 0, ginc = 0, gown = 0, gbelow = 0;
     u64 *mine = lb + (u64)tile * 256 + (tid & 255);
     if (tid < 256) {
         // digit `tid`: exclusive prefix over the waves, tile total
@@ -315,12 +315,39 @@ k_onesweep(const Plan *__restrict__ plan, int pass, const u64 *in, u64 *a, u64 *
     }
     __syncthreads();
     if (tid < 256) {
-        u32 woff = 0, gbelow = 0;
+        u32 woff = 0;
         for (int w = 0; w < wid; ++w) {
             woff += wave_sum[w];
             gbelow += wave_below[w];
         }
         tile_off[tid] = woff + inc - tot;
+        gbelow += ginc - gown;  // keys of lower digits in the whole input
+    }
+    __syncthreads();
+    // the first look-back reads travel while the keys are staged
+    u64 v[LB_WINDOW];
+    bool have = false;
+    if (tid < 256 && tile > 0) {
+#pragma unroll
+        for (int j = 0; j < LB_WINDOW; ++j)
+            v[j] = (long long)tile - 1 - j >= 0
+                       ? __hip_atomic_load(lb + (u64)(tile - 1 - j) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                       : LB_INCL;
+        have = true;
+    }
+    // stage keys in LDS in digit order BEFORE asking for the predecessors' counts: it needs nothing from
+    // them, and they get that much longer to publish (the look-back wait is the largest single cost of
+    // a pass, ~17 of 62 us); key[] and rank[] are dead from here on
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const u32 j = wid * (64 * ITEMS) + r * 64 + lane;
+        if (j < tile_n) {
+            const u32 d = digit_of(key[r], pass);
+            const u32 at = tile_off[d] + wcnt[wid][d] + rank[r];
+            if (at < (u32)TILE) stage[at] = key[r]; else atomicOr(err, 2u);
+        }
+    }
+    if (tid < 256) {
         // decoupled look-back: keys of digit `tid` in all earlier tiles, LB_WINDOW predecessors per
         // round trip (the reads are uncached; windows of 1..8 perform alike, 32 is slower).
         u64 excl = 0;
@@ -329,12 +356,14 @@ k_onesweep(const Plan *__restrict__ plan, int pass, const u64 *in, u64 *a, u64 *
             long long p = (long long)tile - 1;  // nearest predecessor not yet accounted for
             bool done = false;
             while (!done) {
-                u64 v[LB_WINDOW];
+                if (!have) {
 #pragma unroll
-                for (int j = 0; j < LB_WINDOW; ++j)
-                    v[j] = p - j >= 0 ? __hip_atomic_load(lb + (u64)(p - j) * 256 + tid, __ATOMIC_RELAXED,
-                                                          __HIP_MEMORY_SCOPE_AGENT)
-                                      : LB_INCL;
+                    for (int j = 0; j < LB_WINDOW; ++j)
+                        v[j] = p - j >= 0 ? __hip_atomic_load(lb + (u64)(p - j) * 256 + tid, __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_AGENT)
+                                          : LB_INCL;
+                }
+                have = false;
                 int used = 0;
 #pragma unroll
                 for (int j = 0; j < LB_WINDOW; ++j) {
@@ -362,20 +391,9 @@ k_onesweep(const Plan *__restrict__ plan, int pass, const u64 *in, u64 *a, u64 *
             }
             __hip_atomic_store(mine, (excl + tot) | LB_INCL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        base[tid] = (u64)(gbelow + ginc - gown) + excl;
+        base[tid] = (u64)gbelow + excl;
     }
     if (PREFETCH == 2) load_tile(tile1, nkey);
-    __syncthreads();
-    // stage keys in LDS in digit order
-#pragma unroll
-    for (int r = 0; r < ITEMS; ++r) {
-        const u32 j = wid * (64 * ITEMS) + r * 64 + lane;
-        if (j < tile_n) {
-            const u32 d = digit_of(key[r], pass);
-            const u32 at = tile_off[d] + wcnt[wid][d] + rank[r];
-            if (at < (u32)TILE) stage[at] = key[r]; else atomicOr(err, 2u);
-        }
-    }
     if (TICKETS && tid == THREADS - 1) ticket_s[0] = ahead;
     __syncthreads();
     // digit-contiguous runs out to global

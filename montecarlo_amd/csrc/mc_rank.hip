@@ -9,9 +9,10 @@
 //             ping-pong is planned so the last pass lands in keys_sorted.  Each active pass is
 //             ONE kernel that reads every key once and writes it once: a (persistent) workgroup
 //             takes its next tile, ranks its 6144 keys by digit (wave ballots), publishes the
-//             tile's digit counts, obtains the counts of all earlier tiles by decoupled
-//             look-back over the published words, and scatters through LDS so global writes
-//             are digit-contiguous runs.
+//             tile's digit counts, stages the keys in LDS in digit order while its first
+//             look-back reads travel, obtains the counts of all earlier tiles by decoupled
+//             look-back over the published words, and writes the staged keys out so that
+//             global writes are digit-contiguous runs.
 //   scan      positions = inclusive prefix sum of exp2(key - log2 n_global), fp64,
 //             reduce-then-scan over per-workgroup chunks.
 //   query     one lane per test password: upper_bound over the sorted keys.

@@ -23,11 +23,11 @@ import time
 import numpy as np
 import torch
 
-if "--rehearse-on-one-gpu" in sys.argv or "--overlap-score" in sys.argv:
-    # something else runs on the GPU while the sort does (another rank's process, the scoring kernel on a
-    # second stream): the sort takes its tiles by ticket (csrc/mc_rank.hip: the default fixed assignment needs
-    # its whole grid resident, i.e. the GPU to itself); read once when the library loads
-    os.environ.setdefault("MC_SORT_TICKETS", "1")
+if "--rehearse-on-one-gpu" not in sys.argv and "--overlap-score" not in sys.argv:
+    # this process has the GPU to itself and runs the sort alone on its stream: select the sort's
+    # exclusive-GPU tile assignment (csrc/mc_rank.hip; the library's default takes tiles by ticket, which is
+    # safe beside other kernels and slower); read once when the library loads, reported in `config`
+    os.environ.setdefault("MC_SORT_EXCLUSIVE", "1")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

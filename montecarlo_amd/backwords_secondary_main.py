@@ -151,7 +151,7 @@ def join_ranks() -> int:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             torch.cuda.set_device(local % max(n_dev, 1))
-            os.environ.setdefault("MC_SORT_TICKETS", "1")     # ranks share a GPU: csrc/mc_rank.hip, k_onesweep
+            # (ranks share a GPU: fine, the library's sort makes progress under any residency)
             dist.init_process_group("gloo")
     mcd.use_group(True)
     return dist.get_rank()

@@ -100,3 +100,56 @@ def v2_corpus(lines: int, vocab: int = 3000, seed: int = DEFAULT_SEED, stream: i
             fields.append("L" if sgm.isalpha() else "M")
         out.append("\t".join(fields))
     return out
+
+
+def zipf_bpe_dir(path: str, rng: np.random.Generator, mixed: bool = False, structures: int = 400) -> None:
+    """A synthetic BPE-PCFG model directory (format of the reference's bpeX/modelreader.py:15-68) with
+    Zipfian terminals: rows of 10..1e5 terminals, ``structures`` structures (config 4's shape).  With
+    ``mixed`` the directory also holds mixed-class terminal rows (mixed_2/3/4 = tags DM/TM/FM) and
+    structures that use them, which is what sends ``calc_ml2p`` through the wildcard labels and the
+    not_parsed fallback (bpe_simulator.py:72-101,121-128)."""
+    import os
+    for sub in ("grammar", "lower", "upper", "mixed_2", "mixed_3", "mixed_4", "digits", "special"):
+        os.makedirs(os.path.join(path, sub), exist_ok=True)
+    alpha = {"lower": "abcdefghijklmnopqrstuvwxyz", "upper": "ABCDEFGHIJKLMNOPQRSTUVWXYZ", "digits": "0123456789",
+             "special": "!@#$%^&*._"}
+    tag = {"lower": "L", "upper": "U", "digits": "D", "special": "S", "mixed_2": "DM", "mixed_3": "TM",
+           "mixed_4": "FM"}
+    sizes = {"lower": {1: 26, 2: 600, 3: 8000, 4: 60000, 5: 100000, 6: 100000, 7: 50000, 8: 30000},
+             "upper": {1: 26, 2: 300, 3: 2000}, "digits": {1: 10, 2: 100, 3: 1000, 4: 10000, 5: 30000, 6: 50000},
+             "special": {1: 10, 2: 90}}
+    if mixed:
+        both = alpha["lower"] + alpha["digits"]
+        alpha.update({"mixed_2": both, "mixed_3": both + alpha["upper"], "mixed_4": both + alpha["special"]})
+        sizes.update({"mixed_2": {2: 300, 3: 3000, 4: 20000}, "mixed_3": {3: 2000, 5: 20000},
+                      "mixed_4": {4: 5000, 6: 40000}})
+    have = []
+    for sub, by_len in sizes.items():
+        chars = np.array(list(alpha[sub]))
+        for ln, want in by_len.items():
+            cap = len(chars) ** ln
+            n = min(want, cap)
+            terms = set()
+            while len(terms) < n:
+                block = rng.choice(chars, size=(n, ln))
+                terms.update("".join(r) for r in block)
+            terms = sorted(terms)[:n]
+            rng.shuffle(terms)
+            w = 1.0 / np.arange(1, n + 1) ** 1.05
+            w /= w.sum()
+            with open(os.path.join(path, sub, f"{ln}.txt"), "w") as f:
+                for t, p in zip(terms, w):
+                    f.write(f"{t}\t{float(p)!r}\n")
+            have.append((tag[sub], ln))
+    structs = set()
+    while len(structs) < structures:
+        k = int(rng.integers(1, 4))
+        segs = [have[int(i)] for i in rng.integers(0, len(have), size=k)]
+        if all(a[0] != b[0] for a, b in zip(segs, segs[1:])):
+            structs.add("".join(f"{t}{n}" for t, n in segs))
+    structs = sorted(structs)
+    w = 1.0 / np.arange(1, len(structs) + 1) ** 1.1
+    w /= w.sum()
+    with open(os.path.join(path, "grammar", "structures.txt"), "w") as f:
+        for s_, p in zip(structs, w):
+            f.write(f"{s_}\t{float(p)!r}\n")

@@ -38,49 +38,6 @@ def line(name, workload, items, secs, **kw):
                       "items_per_s": items / secs, **kw}), flush=True)
 
 
-def zipf_bpe_dir(path, rng):
-    """A synthetic BPE-PCFG model directory (format of bpeX/modelreader.py:15-68) with Zipfian terminals:
-    rows of 2e3..1e5 terminals, 400 structures."""
-    for sub in ("grammar", "lower", "upper", "mixed_2", "mixed_3", "mixed_4", "digits", "special"):
-        os.makedirs(os.path.join(path, sub), exist_ok=True)
-    alpha = {"lower": "abcdefghijklmnopqrstuvwxyz", "upper": "ABCDEFGHIJKLMNOPQRSTUVWXYZ", "digits": "0123456789",
-             "special": "!@#$%^&*._"}
-    tag = {"lower": "L", "upper": "U", "digits": "D", "special": "S"}
-    sizes = {"lower": {1: 26, 2: 600, 3: 8000, 4: 60000, 5: 100000, 6: 100000, 7: 50000, 8: 30000},
-             "upper": {1: 26, 2: 300, 3: 2000}, "digits": {1: 10, 2: 100, 3: 1000, 4: 10000, 5: 30000, 6: 50000},
-             "special": {1: 10, 2: 90}}
-    have = []
-    for sub, by_len in sizes.items():
-        chars = np.array(list(alpha[sub]))
-        for ln, want in by_len.items():
-            cap = len(chars) ** ln
-            n = min(want, cap)
-            terms = set()
-            while len(terms) < n:
-                block = rng.choice(chars, size=(n, ln))
-                terms.update("".join(r) for r in block)
-            terms = sorted(terms)[:n]
-            rng.shuffle(terms)
-            w = 1.0 / np.arange(1, n + 1) ** 1.05
-            w /= w.sum()
-            with open(os.path.join(path, sub, f"{ln}.txt"), "w") as f:
-                for t, p in zip(terms, w):
-                    f.write(f"{t}\t{float(p)!r}\n")
-            have.append((tag[sub], ln))
-    structs = set()
-    while len(structs) < 400:
-        k = int(rng.integers(1, 4))
-        segs = [have[int(i)] for i in rng.integers(0, len(have), size=k)]
-        if all(a[0] != b[0] for a, b in zip(segs, segs[1:])):
-            structs.add("".join(f"{t}{n}" for t, n in segs))
-    structs = sorted(structs)
-    w = 1.0 / np.arange(1, len(structs) + 1) ** 1.1
-    w /= w.sum()
-    with open(os.path.join(path, "grammar", "structures.txt"), "w") as f:
-        for s_, p in zip(structs, w):
-            f.write(f"{s_}\t{float(p)!r}\n")
-
-
 def main():
     dev = torch.device("cuda")
     N = 10_000_000
@@ -106,7 +63,7 @@ def main():
 
     # config 4: BPE-PCFG sampling and scoring
     with tempfile.TemporaryDirectory() as tmp:
-        zipf_bpe_dir(tmp, np.random.default_rng(4))
+        synth.zipf_bpe_dir(tmp, np.random.default_rng(4))
         b = BpePcfgSim(tmp)
     line("k_sample_bpe", "synthetic BPE-PCFG: 400 structures, terminal rows up to 1e5", N,
          timed(lambda: b._dev.sample(N, 3, out=keys)), entries=b._flat.info[1])

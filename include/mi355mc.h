@@ -377,6 +377,21 @@ size_t mc_rank_workspace_bytes(uint64_t n);
 int mc_rank_build(const double *keys_in, uint64_t n, uint64_t n_global, double *keys_sorted, double *positions,
                   void *workspace, size_t workspace_bytes, void *stream);
 
+/* mc_rank_build for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE: it is the same
+ * computation as mc_rank_build (same kernels, same results bit for bit) with the workspace taken from a
+ * device array built into the library instead of from the caller; inputs and outputs are still the
+ * caller's.  It calls no hipMalloc / hipFree or any allocating routine.  Limits: n <=
+ * MC_RANK_NOALLOC_MAX_KEYS (beyond that MC_ERR_ARG with a message; use mc_rank_build); every GPU the
+ * library runs on holds MC_RANK_NOALLOC_SCRATCH_BYTES of device memory for the array until the process
+ * ends.  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two
+ * threads) race -- serialise them. */
+#define MC_RANK_NOALLOC_MAX_KEYS (1ull << 21)
+#define MC_RANK_NOALLOC_SCRATCH_BYTES (24ull << 20)
+uint64_t mc_rank_noalloc_max_keys(void);
+int mc_rank_build_noalloc(const double *keys_in, uint64_t n, uint64_t n_global, double *keys_sorted,
+                          double *positions, void *stream);
+
 /* ml2p2rank (lib4mc/MonteCarloLib.py:30-32) for t queries: cnt = bisect_right(keys_sorted, x),
  * pos = positions[cnt-1] or 0.0 when cnt == 0 (the caller maps a global cnt of 0 to the
  * reference's `1`, after summing shards). */

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <mutex>
 
 #include "mc_internal.h"
 
@@ -689,6 +690,66 @@ extern "C" int mc_rank_build(const double *keys_in, uint64_t n, uint64_t n_globa
                        logn, (const double *)ws.partials, (const u32 *)err, positions);
     HIP_TRY(hipGetLastError());
     return MC_OK;
+}
+
+// ---- mc_rank_build for callers that cannot allocate --------------------------------------------
+// The workspace of mc_rank_build lives in this file-scope device array instead of a caller's buffer.
+// Host code never passes the array's NAME to a kernel or a memset (on the host it is a stand-in, not a
+// device address): the address is asked for once per device with hipGetSymbolAddress, with that device
+// current, and kept; every GPU the library runs on holds its own copy of the array at its own address
+// until the process ends.
+static __device__ __align__(256) unsigned char mc_rank_scratch[MC_RANK_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+std::mutex g_scratch_mutex;
+void *g_scratch_ptr[64] = {nullptr};  // device address of mc_rank_scratch, per device
+
+int rank_scratch_for_current_device(void **out) {
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) {
+        mc_set_error("mc_rank_build_noalloc: device %d is outside the supported range 0..63", dev);
+        return MC_ERR_ARG;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(mc_rank_scratch)));
+        if (!p) {
+            mc_set_error("mc_rank_build_noalloc: hipGetSymbolAddress returned a null address on device %d", dev);
+            return MC_ERR_HIP;
+        }
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return MC_OK;
+}
+}  // namespace
+
+extern "C" uint64_t mc_rank_noalloc_max_keys(void) { return MC_RANK_NOALLOC_MAX_KEYS; }
+
+extern "C" int mc_rank_build_noalloc(const double *keys_in, uint64_t n, uint64_t n_global, double *keys_sorted,
+                                     double *positions, void *stream) {
+    if (n > MC_RANK_NOALLOC_MAX_KEYS) {
+        mc_set_error("mc_rank_build_noalloc: %llu keys, the built-in scratch holds at most %llu (use mc_rank_build "
+                     "with a caller workspace beyond that)",
+                     (unsigned long long)n, (unsigned long long)MC_RANK_NOALLOC_MAX_KEYS);
+        return MC_ERR_ARG;
+    }
+    if (n && mc_rank_workspace_bytes(n) > (size_t)MC_RANK_NOALLOC_SCRATCH_BYTES) {
+        mc_set_error("mc_rank_build_noalloc: %llu keys need %zu bytes of scratch, the array holds %llu",
+                     (unsigned long long)n, mc_rank_workspace_bytes(n),
+                     (unsigned long long)MC_RANK_NOALLOC_SCRATCH_BYTES);
+        return MC_ERR_WORKSPACE;
+    }
+    void *scratch = nullptr;
+    {
+        int rc = rank_scratch_for_current_device(&scratch);
+        if (rc != MC_OK) return rc;
+    }
+    // every call on this GPU shares the array: mc_rank_build clears the words that must start at zero
+    // (histograms, error word, look-back words) on `stream` before its first kernel
+    return mc_rank_build(keys_in, n, n_global, keys_sorted, positions, scratch, MC_RANK_NOALLOC_SCRATCH_BYTES, stream);
 }
 
 extern "C" int mc_rank_query(const double *keys_sorted, const double *positions, uint64_t n, const double *x,

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Golden run of the reference's secondary-training driver (backwords_secondary_main.py,
-`--strategy samples 2`) -> tests/golden/secondary_main.json.
+"""Golden runs of the reference's secondary-training driver (backwords_secondary_main.py):
+`--strategy samples 2` -> tests/golden/secondary_main.json; `guesses`, `hits` and `auto_hits` ->
+tests/golden/secondary_strategies.json.
 
 Run in the build container only (needs /root/reference):  python tests/golden/make_golden_secondary.py
 
@@ -56,13 +57,24 @@ def sample1_with_stream(self):
 BackWordsSecondaryMonteCarlo.sample1 = sample1_with_stream
 
 
-def main():
+# the other strategies of the driver (reference backwords_secondary_main.py:139-163): guess-number bounds, hit
+# bounds, generated hit bounds -> tests/golden/secondary_strategies.json
+OTHER = {
+    "guesses": ["--strategy", "guesses", "2000", "100000", "--size", "3000", "--threshold", "4",
+                "--secondary-sample", "150"],
+    "hits": ["--strategy", "hits", "30", "60", "--size", "3000", "--threshold", "4"],
+    "auto_hits": ["--strategy", "auto_hits", "2", "15", "100", "--size", "2500", "--threshold", "4",
+                  "--secondary-sample", "100"],
+}
+
+
+def run(args):
     import pickle
-    out = {"meta": {"seed": SEED, "args": ARGS, "train": "train_char.txt", "test": "test_char.txt"}, "files": {}}
+    out = {"meta": {"seed": SEED, "args": args, "train": "train_char.txt", "test": "test_char.txt"}, "files": {}}
     with tempfile.TemporaryDirectory() as tmp:
         save = os.path.join(tmp, "save")
         sys.argv = ["backwords_secondary_main.py", "-i", os.path.join(HERE, "train_char.txt"),
-                    "-t", os.path.join(HERE, "test_char.txt"), "-s", save] + ARGS
+                    "-t", os.path.join(HERE, "test_char.txt"), "-s", save] + args
         random.seed(SEED)
         ref_main.wrapper()
         for name in sorted(os.listdir(save)):
@@ -80,9 +92,19 @@ def main():
                     cfg = json.load(f)
                 cfg["training_list"] = cfg["training_list"][1:]          # [0] is an absolute path
                 out["files"][name] = cfg
+    return out
+
+
+def main():
+    out = run(ARGS)
     with open(os.path.join(HERE, "secondary_main.json"), "w") as f:
         json.dump(out, f, ensure_ascii=True, separators=(",", ":"))
     print({k: (len(v) if isinstance(v, str) else v) for k, v in out["files"].items()})
+    others = {name: run(args) for name, args in OTHER.items()}
+    with open(os.path.join(HERE, "secondary_strategies.json"), "w") as f:
+        json.dump(others, f, ensure_ascii=True, separators=(",", ":"))
+    for name, o in others.items():
+        print(name, {k: (len(v) if isinstance(v, str) else v) for k, v in o["files"].items()})
 
 
 if __name__ == "__main__":

@@ -1,5 +1,5 @@
 """Compares the files a `backwords_secondary_main` run saved with the reference's own run
-(tests/golden/secondary_main.json).  Shared by the GPU test and scripts/rehearse_secondary.py."""
+(tests/golden/secondary_main.json, secondary_strategies.json).  Shared by the GPU test and scripts/rehearse_secondary.py."""
 import hashlib
 import json
 import os
@@ -10,6 +10,9 @@ REL = 1e-9
 
 def check_saved(save: str, fx: dict):
     assert sorted(os.listdir(save)) == sorted(fx["files"])
+    # `samples` strategy: a cracked password's guess number is its place among the sampled strings (exact);
+    # the other strategies write the Monte Carlo estimate there (prefix sums: 1e-9 relative)
+    by_samples = "samples" in fx["meta"]["args"]
     for name, want in fx["files"].items():
         path = os.path.join(save, name)
         if name.endswith(".pickle"):
@@ -22,7 +25,7 @@ def check_saved(save: str, fx: dict):
                 cfg = json.load(f)
             cfg["training_list"] = cfg["training_list"][1:]
             assert cfg == want
-        elif name in ("iter_result.txt", "sectional_result.txt"):
+        elif name in ("iter_result.txt", "sectional_result.txt") or (name.startswith("cracked-") and not by_samples):
             # guess numbers come from the prefix sums (1e-9 relative, ceil may flip on an exact integer)
             with open(path, newline="") as f:
                 got_lines = f.read().split("\n")

@@ -183,6 +183,24 @@ def test_secondary_main_matches_reference_run(tmp_path):
     check_saved(save, fx)
 
 
+@pytest.mark.parametrize("strategy", ["guesses", "hits", "auto_hits"])
+def test_secondary_main_other_strategies_match_reference_run(tmp_path, strategy):
+    """`--strategy guesses <g1> <g2>`, `hits <h1> <h2>` and `auto_hits <factor> <base> <termination>` of the
+    config-5 driver (reference backwords_secondary_main.py:139-163,70): every output file against the
+    reference's own run of the same command (golden/secondary_strategies.json)."""
+    import os
+    import random
+    from conftest import GOLDEN
+    from montecarlo_amd import backwords_secondary_main as main
+    fx = golden("secondary_strategies.json")[strategy]
+    save = str(tmp_path / "save")
+    random.seed(fx["meta"]["seed"])
+    main.wrapper(["-i", os.path.join(GOLDEN, fx["meta"]["train"]), "-t", os.path.join(GOLDEN, fx["meta"]["test"]),
+                  "-s", save] + fx["meta"]["args"])
+    from secondary_check import check_saved
+    check_saved(save, fx)
+
+
 def test_plugin_surface_matches_reference_run(train_char):
     """sample -> MonteCarloLib -> parse_file -> ml2p_iter2gc -> write2, the whole driver of
     backwords_simulator.py:90-94, against the reference's recorded run (rank.json)."""
@@ -209,8 +227,16 @@ def test_plugin_surface_matches_reference_run(train_char):
     assert exact >= len(gc) - 2                                        # ceil() may flip on an exact integer
     buf = io.StringIO()
     mc.write2(buf)
-    if exact == len(gc):
-        assert buf.getvalue() == fx["write2"]
+    # every line of write2 against the reference's text; a line whose rank flipped (<= 2 of them, above) is
+    # compared with its rank field taken out
+    got_lines, want_lines = buf.getvalue().split("\n"), fx["write2"].split("\n")
+    assert len(got_lines) == len(want_lines) == len(gc) + 1 and got_lines[-1] == want_lines[-1] == ""
+    for g, w, a, b in zip(gc, fx["gc"], got_lines, want_lines):
+        if g[3] == int(w[3]):
+            assert a == b
+        else:
+            fa, fb = a.split("\t"), b.split("\t")
+            assert fa[:3] + fa[4:] == fb[:3] + fb[4:] and fa[3] == str(g[3])
     gc0 = mc.ml2p_iter2gc(scored, add1=False)
     assert sum(1 for g, w in zip(gc0, fx["gc_add0_ranks"]) if g[3] == int(w)) >= len(gc0) - 2
     # list input: uploaded, sorted in place on the device, same numbers

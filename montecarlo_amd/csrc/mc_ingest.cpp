@@ -9,6 +9,7 @@
 #include "mc_internal.h"
 
 #include <cstdio>
+#include <charconv>
 #include <cstring>
 
 namespace {
@@ -206,13 +207,38 @@ extern "C" int64_t mc_format_gc(const char *pwds_utf8, size_t bytes, uint64_t n,
         }
         std::memcpy(dst + out, pwds_utf8 + at, len);
         out += len;
-        const int w = std::snprintf(dst + out, 120, "\t%.8f\t%lld\t%lld\t%lld\t%5.2f\n", mlp[i], (long long)appearance[i],
-                                    (long long)rank[i], (long long)cracked[i], ratio[i]);
-        if (w < 0 || w >= 120) {
+        // std::to_chars: correctly rounded like printf / Python's format(), and independent of the process
+        // locale (a host that called setlocale(LC_NUMERIC, "de_DE") would get decimal commas from printf)
+        char *p = dst + out, *const lim = dst + out + 119;
+        bool ok = true;
+        auto put_f = [&](double v, int prec, int width) {
+            *p++ = '\t';
+            char tmp[400];
+            auto r = std::to_chars(tmp, tmp + sizeof tmp, v, std::chars_format::fixed, prec);
+            const size_t m = (size_t)(r.ptr - tmp);
+            const size_t pad = m < (size_t)width ? (size_t)width - m : 0;
+            if (r.ec != std::errc() || p + pad + m > lim) { ok = false; return; }
+            std::memset(p, ' ', pad);
+            std::memcpy(p + pad, tmp, m);
+            p += pad + m;
+        };
+        auto put_i = [&](long long v) {
+            *p++ = '\t';
+            auto r = std::to_chars(p, lim, v);
+            if (r.ec != std::errc()) { ok = false; return; }
+            p = r.ptr;
+        };
+        put_f(mlp[i], 8, 0);
+        if (ok) put_i((long long)appearance[i]);
+        if (ok) put_i((long long)rank[i]);
+        if (ok) put_i((long long)cracked[i]);
+        if (ok) put_f(ratio[i], 2, 5);
+        if (!ok) {
             mc_set_error("mc_format_gc: a line's numbers do not fit 120 characters");
             return MC_ERR_ARG;
         }
-        out += (size_t)w;
+        *p++ = '\n';
+        out = (size_t)(p - dst);
         at = end + 1;
     }
     return (int64_t)out;

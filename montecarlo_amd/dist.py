@@ -95,8 +95,18 @@ def combine_positions(pos: torch.Tensor, group=None) -> torch.Tensor:
     return pos
 
 
+def raise_on_poisoned(pos: torch.Tensor) -> None:
+    """A rank build that failed on ANY shard poisons that shard's positions with NaN (csrc/mc_rank.hip: error
+    word); NaN survives the SUM, so every rank sees it here.  It must not be read as "no sample counted"
+    (NaN > 0 is False, which would turn every guess number into 1)."""
+    if bool(torch.isnan(pos).any()):
+        raise RuntimeError("rank estimation failed on at least one shard: the summed positions contain NaN "
+                           "(mc_rank_build reported an error on its device, or a query key was NaN)")
+
+
 def estimates_from_positions(pos: torch.Tensor) -> torch.Tensor:
     """``positions[idx-1] if idx > 0 else 1`` from the summed positions alone."""
+    raise_on_poisoned(pos)
     return torch.where(pos > 0, pos, torch.ones_like(pos))
 
 

@@ -54,7 +54,12 @@ class MonteCarloLib:
             # every weight is positive: the summed position is > 0 exactly when some shard counted a sample
             torch.distributed.all_reduce(pos, group=self.__group)
             cnt = (pos > 0).to(torch.int64)
-        return pos.cpu().numpy(), cnt.cpu().numpy()
+        pos_h = pos.cpu().numpy()
+        if numpy.isnan(pos_h).any() and not numpy.isnan(numpy.asarray(xs, dtype=numpy.float64)).any():
+            # a failed build poisons positions with NaN (on any shard: NaN survives the sum); never a guess number
+            raise RuntimeError("rank estimation failed: positions contain NaN (mc_rank_build reported an error "
+                               "on this device or on another shard)")
+        return pos_h, cnt.cpu().numpy()
 
     def ml2p2rank(self, minus_log_prob):
         pos, cnt = self.__estimates([minus_log_prob])
@@ -149,6 +154,8 @@ def _format_native(gc, cols=None) -> "str | None":
         return None
     if not (numpy.isfinite(mlp).all() and numpy.isfinite(ratio).all()):
         return None                                            # (C prints a NaN's sign, Python does not)
+    if float(numpy.abs(mlp).max()) >= 1e15 or float(numpy.abs(ratio).max()) >= 1e15:
+        return None                                            # (wider than the native writer's 120 characters)
     mlp, apps, rank, crk, ratio = (numpy.ascontiguousarray(x) for x in (mlp, apps, rank, crk, ratio))
     out = numpy.empty(len(blob) + 120 * n, dtype=numpy.uint8)           # (not zero-filled)
     vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731

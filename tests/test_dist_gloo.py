@@ -121,3 +121,32 @@ def test_sampled_pwds_merge_over_ranks(tmp_path):
         want.setdefault(pwd, [x, 0])[1] += 1
     assert [tuple(r) for r in got[0]["merged"]] == [(p, x, c) for p, (x, c) in want.items()]
     assert sum(c for _, _, c in got[0]["merged"]) == n_global
+
+
+def _poison_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from montecarlo_amd import dist as mcd
+    pos = torch.tensor([0.0, 3.5, 7.25], dtype=torch.float64)
+    if rank == 1:
+        pos[1] = float("nan")                                  # what a failed rank build leaves in `positions`
+    mcd.combine_positions(pos)
+    try:
+        mcd.estimates_from_positions(pos)
+        verdict = "no error"
+    except RuntimeError as exc:
+        verdict = str(exc)
+    with open(os.path.join(out_dir, f"verdict{rank}.txt"), "w") as f:
+        f.write(verdict)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_nan_partial_from_one_shard_raises_on_every_rank(tmp_path):
+    """A rank build that failed on one shard (NaN positions) must not turn into guess number 1 once the
+    shards are summed: every rank raises."""
+    world = 2
+    mp.spawn(_poison_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert "NaN" in open(tmp_path / f"verdict{r}.txt").read()

@@ -201,6 +201,29 @@ def test_secondary_main_other_strategies_match_reference_run(tmp_path, strategy)
     check_saved(save, fx)
 
 
+@pytest.mark.timeout(170)
+def test_secondary_main_sharded_over_two_ranks(tmp_path):
+    """Config 5 with the sample set sharded over ranks: `backwords_secondary_main --strategy samples 2` under
+    torch.distributed.run with 2 ranks (they share this box's GPU and talk over gloo; on a multi-GPU node the
+    same code runs one rank per GPU over RCCL).  The product sampler draws each rank's share of the global
+    sample ids (`MonteCarlo.sample` under `dist.use_group`), the `sampled_pwds` dicts are merged, `MonteCarloLib`
+    all-reduces its queries: rank 0's files must equal the reference's single-process run."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, TQDM_DISABLE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "scripts", "rehearse_secondary.py")]
+    done = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=150)
+    assert done.returncode == 0, done.stdout[-2000:] + done.stderr[-4000:]
+    assert "rehearse_secondary ok: 2 rank(s)" in done.stdout
+
+
 def test_plugin_surface_matches_reference_run(train_char):
     """sample -> MonteCarloLib -> parse_file -> ml2p_iter2gc -> write2, the whole driver of
     backwords_simulator.py:90-94, against the reference's recorded run (rank.json)."""

@@ -366,16 +366,25 @@ int mc_score_bpe(mc_model *m, const uint32_t *cps, const uint8_t *cls, const uin
  * positions are outputs [n]; keys_in is left untouched.  n_global = total samples over all
  * GPUs (= n on one GPU): each shard weights with the global n so that per-shard results add.
  *
- * The sort's persistent grid is sized to what the GPU holds at once and assigns tiles by workgroup index:
- * it wants the GPU to itself while it runs (about 0.5 ms per 1e7 keys).  A kernel that holds part of the GPU
- * at the same time (another stream, another process) can leave it with workgroups that cannot start; the
- * build then stalls until its spin bound and returns NaN positions.  Set MC_SORT_TICKETS=1 in the
- * environment (read once, before the first build) where that cannot be ruled out: tiles are then taken from a
- * counter, which is safe under any residency and ~17 % slower.
+ * The sort (csrc/mc_sort.hip) counts the copies of heavily repeated values instead of moving them and
+ * sends the rest through MSD radix levels; no workgroup of it ever waits for another one, so the build
+ * makes progress beside any other work on the GPU (other streams, other processes) and needs no
+ * residency guarantee.  The workspace holds two key buffers and the sort's tables (about 2.5 x the keys).
+ * Failure is loud: if a table overflows or a count does not match its keys (the caller overwrote keys_in
+ * while the build ran), nothing is written outside the buffers, `positions` is filled with NaN and
+ * mc_rank_check reports it.
  */
 size_t mc_rank_workspace_bytes(uint64_t n);
 int mc_rank_build(const double *keys_in, uint64_t n, uint64_t n_global, double *keys_sorted, double *positions,
                   void *workspace, size_t workspace_bytes, void *stream);
+
+/* Synchronises `stream` and reads the status of the last mc_rank_build that used `workspace` for n keys:
+ * MC_OK, or MC_ERR_WORKSPACE when the build failed on the device (positions are NaN then).  info (may be
+ * NULL) receives {error word, heavy values found, tail keys, radix levels used, finish tiles, segments, 0, 0}.
+ * No counterpart in the reference (its list.sort() cannot fail). */
+int mc_rank_check(const void *workspace, uint64_t n, void *stream, uint64_t info[8]);
+/* Test hook: while on, every mc_rank_build takes its device-side failure path (tables "overflow" at once). */
+void mc_rank_debug_fail(int on);
 
 /* mc_rank_build for callers that cannot allocate device memory (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE: it is the same
@@ -386,7 +395,7 @@ int mc_rank_build(const double *keys_in, uint64_t n, uint64_t n_global, double *
  * library runs on holds MC_RANK_NOALLOC_SCRATCH_BYTES of device memory for the array until the process
  * ends.  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two
  * threads) race -- serialise them. */
-#define MC_RANK_NOALLOC_MAX_KEYS (1ull << 21)
+#define MC_RANK_NOALLOC_MAX_KEYS (1ull << 20)
 #define MC_RANK_NOALLOC_SCRATCH_BYTES (24ull << 20)
 uint64_t mc_rank_noalloc_max_keys(void);
 int mc_rank_build_noalloc(const double *keys_in, uint64_t n, uint64_t n_global, double *keys_sorted,

@@ -1,0 +1,21 @@
+// Internal: the key sort behind mc_rank_build (csrc/mc_sort.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+// Bytes of device workspace mc_sort_keys needs for n keys (two key buffers + control tables).
+size_t mc_sort_workspace_bytes(uint64_t n);
+
+// Sorts n u64 keys (fp64 bit patterns of non-negative doubles: IEEE bit order = numeric order) from `in`
+// (left untouched) into `out`, ascending, asynchronously on `stream`.  Allocates nothing.  *err_word_out
+// receives the device address of the sort's error word: non-zero after the sort means a table overflowed
+// and `out` is not sorted (the caller poisons what it derives from it).  debug_fail != 0 forces that
+// failure path (tests).
+int mc_sort_keys(const uint64_t *in, uint64_t n, uint64_t *out, void *workspace, size_t workspace_bytes,
+                 uint32_t **err_word_out, int debug_fail, hipStream_t stream);
+
+// Host copy of the sort's counters after `stream` has drained: {error word, heavy values, tail keys,
+// levels used, finish tiles, segments created, 0, 0}.
+int mc_sort_info(const void *workspace, uint64_t n, uint64_t info[8], hipStream_t stream);

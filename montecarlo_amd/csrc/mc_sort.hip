@@ -1,0 +1,1172 @@
+// The key sort behind mc_rank_build (gfx950): replaces `minus_log_prob_list.sort()` of
+// MonteCarloLib.__init__, reference lib4mc/MonteCarloLib.py:11.
+//
+// Sampled -log2 p are not generic keys.  A password model puts most of its mass on few strings, so most
+// samples REPEAT a value (headline model: 1e7 samples hold 1.7e5 distinct values, 76 % of the samples are
+// copies of 240 of them), and the sort is keys-only: equal keys are indistinguishable, nothing has to be
+// stable.  The sort is built for that and degrades gracefully to any key set:
+//
+//   k_sniff    one workgroup samples 4096 keys and lists the values seen at least 4 times ("heavy", <= 1024,
+//              sorted).
+//   k_strip    one read of all keys: a key equal to a heavy value is COUNTED, not moved (lookup in an LDS hash
+//              set); the others (the "tail") are written compacted, region by region, and their top-byte
+//              histograms are taken on the way.  No heavy values found: nothing is copied.
+//   levels     MSD radix passes over the tail, 8 bits each, most significant VARYING bits first: k_count
+//              takes per-segment digit histograms and the OR / AND of every bin's keys, k_scatter moves the keys
+//              into their bins and plans the next level: a bin of <= 4096 keys (or several neighbours that fit
+//              together) becomes a "finish tile", a larger bin whose keys are all equal is cut into finish
+//              tiles as it is, any other larger bin becomes a segment of the next level, its digit placed at
+//              its own highest varying bit.  Destinations inside a bin are reserved with one atomic add per
+//              (tile, bin) -- the order inside a bin is irrelevant -- so no workgroup ever waits for another
+//              one: there is no look-back chain, no spinning, no residency assumption; every kernel makes
+//              progress beside any other work on the GPU.
+//   k_finish   sorts a tile of <= 4096 keys in LDS: buckets them linearly over [min, max] (4096 buckets, ~1
+//              key each), ranks inside small buckets by counting, walks the distinct values of large ones, and
+//              writes every key at its final index = its rank in the tail + the copies of smaller heavy values.
+//   k_fill     writes the runs of the heavy values into the gaps left for them.
+//
+// All hand-offs between workgroups go through kernel boundaries on the stream.  Every store that depends on a
+// count is bounds-checked and every table has a capacity check; a violation sets the error word (the caller
+// poisons its result) instead of writing outside a buffer.
+#include "mc_sort.h"
+
+#include <cstdlib>
+
+#include "mc_internal.h"
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            mc_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return MC_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+namespace {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+constexpr int CAP = 4096;          // keys a finish tile sorts in LDS; larger bins go one level deeper
+constexpr int TILE = 4096;         // keys per count / scatter tile
+constexpr int WG = 512;            // threads of the strip / count / scatter / finish workgroups
+constexpr int ITEMS = TILE / WG;   // keys per lane and tile
+constexpr int NWAVE = WG / 64;
+constexpr int REGION = 16384;      // keys per strip region (its tail is stored at the region's own offset)
+constexpr int SNIFF_S = 8192, SNIFF_SLOTS = 12288, SNIFF_MIN = 4, SNIFF_THREADS = 1024;
+constexpr int H_MAX = 1024, HSET = 2048;
+constexpr int HOT = 8;             // heavy values compared against directly, lane-private counters (no LDS at all)
+constexpr int COPIES = 4;          // lane-sliced copies of LDS histograms: lanes l, l+4, ... share one
+constexpr int MAX_LEVELS = 8;      // 64 bits / 8
+constexpr int BINS = 4096;         // buckets of a finish tile
+constexpr int SMALL_GROUP = 32;    // bucket sizes ranked by counting, lane per key
+constexpr u64 EMPTY = ~0ull;
+
+enum { ERR_SEG = 1u, ERR_TILE = 2u, ERR_FT = 4u, ERR_RANGE = 8u, ERR_DEBUG = 16u, ERR_LEVEL = 32u };
+enum { SRC_IN = 0, SRC_B = 1, SRC_C = 2 };
+
+struct Ctl {
+    u32 err;
+    u32 n_heavy;
+    u32 n_tail;
+    u32 levels_used;
+    u64 or_all, nor_all;  // OR of the tail keys, OR of their complements (AND = ~nor_all)
+    u32 nseg[MAX_LEVELS + 1];
+    u32 ntile[MAX_LEVELS + 1];
+    u32 nft;
+    u32 segs_total;
+};
+
+struct Seg {
+    u32 off, size, shift, pad;
+};
+struct HistRow {
+    u32 cnt[256];   // keys per bin
+    u32 cur[256];   // scatter cursor of the bin (reservations)
+    u64 orv[256];   // OR of the bin's keys
+    u64 norv[256];  // OR of their complements; both 0 = not collected (root level)
+};
+struct TileRef {
+    u32 seg, k;
+};
+struct FTile {
+    u32 off, size, src, pad;
+};
+
+struct Ws {
+    Ctl *ctl;
+    u64 *heavy;      // [H_MAX] sorted heavy values
+    u32 *hcnt;       // [H_MAX] their copies
+    u32 *gap;        // [H_MAX + 1] tail keys with exactly g heavy values below them
+    u64 *hotv;       // [HOT] the heavy values seen most often in the sample (EMPTY: none) ...
+    u32 *hoti;       // [HOT] ... and their indices in `heavy`
+    HistRow *root;   // [2]: digit at bits 48..55, digit at bits 56..63 (tail keys)
+    u32 *rcnt;       // [regions] tail keys of each region
+    Seg *segs[2];
+    HistRow *rows[2];
+    TileRef *tiles[2];
+    FTile *ft;
+    const u64 *in;
+    u64 *A, *B, *C;
+    u32 n, regions;
+    u32 cap_seg, cap_tile, cap_ft;
+    u32 exp;  // experiment switches (MC_SORT_EXP, development only; results are WRONG when set)
+};
+
+__device__ __forceinline__ u32 hset_hash(u64 k) { return (u32)((k * 0x9E3779B97F4A7C15ull) >> 40); }
+
+// exclusive prefix of v over the workgroup (every thread calls); `wtot` holds NWAVE words
+__device__ __forceinline__ u32 wg_excl_scan(u32 v, u32 *wtot, u32 &total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    u32 inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads();  // wtot may still be read from the previous call
+    if (lane == 63) wtot[wid] = inc;
+    __syncthreads();
+    u32 off = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < NWAVE; ++i) {
+        const u32 t = wtot[i];
+        if (i < wid) off += t;
+        tot += t;
+    }
+    total = tot;
+    return off + inc - v;
+}
+
+__device__ __forceinline__ u64 wave_or(u64 v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v |= __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ u64 wave_min(u64 v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        const u64 t = __shfl_xor(v, o);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ u64 wave_max(u64 v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        const u64 t = __shfl_xor(v, o);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ u32 wave_sum(u32 v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// LDS histogram add that returns the key's rank inside its (bin, copy) slot.  Sampled keys repeat, and lanes
+// that add to ONE LDS word in one instruction are served one after the other (measured: that, not memory, set
+// the pace of the first version of every kernel here).  So: the lanes whose KEY equals the first pending lane's
+// key are served by that lane with one add, into that lane's slot (twice); whoever is left adds for itself.
+// `slot` comes back as the slot the key was counted in.
+__device__ __forceinline__ u32 lds_rank_add(u32 *bins, u32 &slot, u64 key, bool valid, int lane) {
+    u32 rank = 0;
+    u64 rem = __ballot(valid);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        if (rem == 0) break;  // (wave-uniform)
+        const int leader = __ffsll((long long)rem) - 1;
+        const u64 k0 = __shfl(key, leader);
+        const u32 s0 = __shfl(slot, leader);
+        const u64 same = __ballot(valid && key == k0) & rem;
+        u32 base = 0;
+        if (lane == leader) base = atomicAdd(&bins[s0], (u32)__popcll(same));
+        base = __shfl(base, leader);
+        if ((same >> lane) & 1ull) {
+            rank = base + (u32)__popcll(same & ((1ull << lane) - 1ull));
+            slot = s0;
+        }
+        rem &= ~same;
+    }
+    if ((rem >> lane) & 1ull) rank = atomicAdd(&bins[slot], 1u);
+    return rank;
+}
+
+// ---- heavy values -------------------------------------------------------------------------------------
+// One workgroup: SNIFF_S keys at a fixed stride into an LDS hash table (value, occurrences); the values seen
+// SNIFF_MIN times or more (at most H_MAX: the bar is raised until they fit) are the heavy values, written in
+// ascending order; the HOT most frequent of them are listed once more for k_strip's direct compares.
+__global__ void __launch_bounds__(SNIFF_THREADS) k_sniff(Ws w) {
+    __shared__ u64 tk[SNIFF_SLOTS];
+    __shared__ u32 tc[SNIFF_SLOTS / 2];  // two 16-bit counts per word
+    __shared__ u64 list[H_MAX];
+    __shared__ u32 lcnt[H_MAX];
+    __shared__ u32 nlist;
+    const u32 n = w.n;
+    const int tid = threadIdx.x;
+    if (n < (u32)SNIFF_S * 8) return;  // small inputs: no heavy values (n_heavy stays 0)
+    for (int i = tid; i < SNIFF_SLOTS; i += SNIFF_THREADS) tk[i] = EMPTY;
+    for (int i = tid; i < SNIFF_SLOTS / 2; i += SNIFF_THREADS) tc[i] = 0;
+    __syncthreads();
+    const u32 stride = n / SNIFF_S;
+    u64 k[SNIFF_S / SNIFF_THREADS];
+#pragma unroll
+    for (int q = 0; q < SNIFF_S / SNIFF_THREADS; ++q) k[q] = w.in[(u64)(q * SNIFF_THREADS + tid) * stride + stride / 2];
+#pragma unroll
+    for (int q = 0; q < SNIFF_S / SNIFF_THREADS; ++q) {
+        if (k[q] == EMPTY) continue;
+        u32 s = (u32)(((u64)hset_hash(k[q]) * SNIFF_SLOTS) >> 24);  // hset_hash has 24 bits
+        for (;;) {  // at most SNIFF_S of SNIFF_SLOTS slots are ever taken: the probe ends
+            const u64 old = atomicCAS(&tk[s], EMPTY, k[q]);
+            if (old == EMPTY || old == k[q]) {
+                atomicAdd(&tc[s >> 1], 1u << (16 * (s & 1u)));
+                break;
+            }
+            s = s + 1 == (u32)SNIFF_SLOTS ? 0u : s + 1;
+        }
+    }
+    u32 bar = SNIFF_MIN;
+    for (;;) {  // (uniform: every thread sees the same nlist)
+        __syncthreads();
+        if (tid == 0) nlist = 0;
+        __syncthreads();
+        u32 mine = 0;
+        for (int i = tid; i < SNIFF_SLOTS; i += SNIFF_THREADS) mine += ((tc[i >> 1] >> (16 * (i & 1))) & 0xFFFFu) >= bar;
+        if (mine) atomicAdd(&nlist, mine);
+        __syncthreads();
+        if (nlist <= (u32)H_MAX) break;
+        ++bar;
+    }
+    const u32 H = nlist;
+    __syncthreads();
+    if (tid == 0) nlist = 0;
+    __syncthreads();
+    for (int i = tid; i < SNIFF_SLOTS; i += SNIFF_THREADS) {
+        const u32 c = (tc[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+        if (c >= bar) {
+            const u32 p = atomicAdd(&nlist, 1u);
+            list[p] = tk[i];  // p < H <= H_MAX
+            lcnt[p] = c;
+        }
+    }
+    __syncthreads();
+    for (u32 i = tid; i < H; i += SNIFF_THREADS) {  // the values are distinct: rank = position
+        const u64 v = list[i];
+        const u32 c = lcnt[i];
+        u32 r = 0, by_count = 0;
+        for (u32 j = 0; j < H; ++j) {
+            r += list[j] < v ? 1u : 0u;
+            by_count += (lcnt[j] > c || (lcnt[j] == c && j < i)) ? 1u : 0u;
+        }
+        w.heavy[r] = v;
+        if (by_count < (u32)HOT) {
+            w.hotv[by_count] = v;
+            w.hoti[by_count] = r;
+        }
+    }
+    if (tid == 0) w.ctl->n_heavy = H;
+}
+
+// ---- strip: count the copies of heavy values, compact the tail ------------------------------------------
+__global__ void __launch_bounds__(WG) k_strip(Ws w) {
+    __shared__ u64 hk[HSET];
+    __shared__ u32 hi[HSET];
+    __shared__ u32 hc[H_MAX];
+    __shared__ u32 h48[256 * COPIES], h56[256];
+    __shared__ u32 roff;
+    __shared__ u64 red[2 * NWAVE];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const u32 H = w.ctl->n_heavy;
+    const u32 n = w.n;
+    for (int i = tid; i < HSET; i += WG) hk[i] = EMPTY;
+    for (int i = tid; i < H_MAX; i += WG) hc[i] = 0;
+    for (int i = tid; i < 256 * COPIES; i += WG) h48[i] = 0;
+    if (tid < 256) h56[tid] = 0;
+    __syncthreads();
+    for (u32 i = tid; i < H; i += WG) {
+        const u64 v = w.heavy[i];
+        u32 s = hset_hash(v) & (HSET - 1);
+        for (;;) {  // H <= HSET / 2 distinct values
+            const u64 old = atomicCAS(&hk[s], EMPTY, v);
+            if (old == EMPTY) {
+                hi[s] = i;
+                break;
+            }
+            s = (s + 1) & (HSET - 1);
+        }
+    }
+    u64 hot[HOT];
+    u32 hotc[HOT];
+    const u32 nhot = H < (u32)HOT ? H : (u32)HOT;  // k_sniff filled hotv / hoti [0, nhot)
+#pragma unroll
+    for (int i = 0; i < HOT; ++i) {
+        hot[i] = (u32)i < nhot ? w.hotv[i] : 0ull;  // (uniform: scalar registers)
+        hotc[i] = 0;
+    }
+    __syncthreads();
+    u64 o = 0, no = 0;
+    u32 tail_total = 0;  // (thread 0)
+    const u32 cp = (u32)(lane & (COPIES - 1)) * 256u;
+    for (u32 r = blockIdx.x; r < w.regions; r += gridDim.x) {
+        const u64 lo = (u64)r * REGION;
+        const u32 rn = (u32)(n - lo < (u64)REGION ? n - lo : (u64)REGION);
+        if (tid == 0) roff = 0;
+        __syncthreads();
+        u64 k[ITEMS], nk[ITEMS];
+#pragma unroll
+        for (int q = 0; q < ITEMS; ++q) {
+            const u32 j = q * WG + tid;
+            nk[q] = j < rn ? w.in[lo + j] : EMPTY;
+        }
+        for (u32 c0 = 0; c0 < rn; c0 += TILE) {
+#pragma unroll
+            for (int q = 0; q < ITEMS; ++q) k[q] = nk[q];
+            if (c0 + TILE < rn) {  // the next tile travels while this one is looked up
+#pragma unroll
+                for (int q = 0; q < ITEMS; ++q) {
+                    const u32 j = c0 + TILE + q * WG + tid;
+                    nk[q] = j < rn ? w.in[lo + j] : EMPTY;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < ITEMS; ++q) {
+                const u32 j = c0 + q * WG + tid;
+                bool tail = j < rn;
+                if (tail && H) {
+                    bool is_hot = false;
+#pragma unroll
+                    for (int i = 0; i < HOT; ++i) {
+                        const bool hit = (u32)i < nhot && k[q] == hot[i];
+                        hotc[i] += hit ? 1u : 0u;
+                        is_hot |= hit;
+                    }
+                    if (is_hot) {
+                        tail = false;
+                    } else if (!(w.exp & 8u)) {
+                        u32 s = hset_hash(k[q]) & (HSET - 1);
+                        for (;;) {
+                            const u64 t = hk[s];
+                            if (t == k[q]) {
+                                if (t != EMPTY) {  // (a key equal to the empty marker is never heavy)
+                                    atomicAdd(&hc[hi[s]], 1u);
+                                    tail = false;
+                                }
+                                break;
+                            }
+                            if (t == EMPTY) break;
+                            s = (s + 1) & (HSET - 1);
+                        }
+                    }
+                }
+                const u64 mask = __ballot(tail);
+                if (mask) {
+                    const int first = __ffsll((long long)mask) - 1;
+                    if (H) {  // compact (no heavy values: the region is its own tail and stays where it is)
+                        u32 base = 0;
+                        if (lane == first) base = atomicAdd(&roff, (u32)__popcll(mask));
+                        base = __shfl(base, first);
+                        if (tail) w.B[lo + base + (u32)__popcll(mask & ((1ull << lane) - 1ull))] = k[q];
+                    }
+                    // top-byte histograms of the tail: bits 56..63 are one value almost always
+                    const u32 d56 = (u32)(k[q] >> 56), d56_0 = __shfl(d56, first);
+                    const u64 same = __ballot(tail && d56 == d56_0);
+                    if (lane == first) atomicAdd(&h56[d56_0], (u32)__popcll(same));
+                    if (tail) {
+                        if (d56 != d56_0) atomicAdd(&h56[d56], 1u);
+                        atomicAdd(&h48[cp + ((u32)(k[q] >> 48) & 255u)], 1u);
+                        o |= k[q];
+                        no |= ~k[q];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const u32 m = H ? roff : rn;
+            w.rcnt[r] = m;
+            tail_total += m;
+        }
+        __syncthreads();
+    }
+    o = wave_or(o);
+    no = wave_or(no);
+#pragma unroll
+    for (int i = 0; i < HOT; ++i) hotc[i] = wave_sum(hotc[i]);
+    if (lane == 0) {
+        red[wid] = o;
+        red[NWAVE + wid] = no;
+        if (H) {
+#pragma unroll
+            for (int i = 0; i < HOT; ++i)
+                if (hotc[i]) atomicAdd(&hc[w.hoti[i]], hotc[i]);  // (hotc > 0 only for i < nhot)
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        u64 a = 0, b = 0;
+        for (int i = 0; i < NWAVE; ++i) {
+            a |= red[i];
+            b |= red[NWAVE + i];
+        }
+        if (a | b) {
+            atomicOr(&w.ctl->or_all, a);
+            atomicOr(&w.ctl->nor_all, b);
+        }
+        if (tail_total) atomicAdd(&w.ctl->n_tail, tail_total);
+    }
+    if (w.exp & 2u) return;
+    if (tid < 256) {
+        u32 v = 0;
+#pragma unroll
+        for (int c = 0; c < COPIES; ++c) v += h48[c * 256 + tid];
+        if (v) atomicAdd(&w.root[0].cnt[tid], v);
+        if (h56[tid]) atomicAdd(&w.root[1].cnt[tid], h56[tid]);
+    }
+    for (u32 i = tid; i < H; i += WG)
+        if (hc[i]) atomicAdd(&w.hcnt[i], hc[i]);
+}
+
+// ---- one MSD level --------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WG) k_count(Ws w, int level) {
+    __shared__ u32 lc[256 * COPIES];
+    __shared__ u64 lor[256 * COPIES], lnor[256 * COPIES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int set = level & 1;
+    if (w.ctl->err) return;  // a table overflowed in an earlier kernel: its entries are not to be trusted
+    const u32 nt = w.ctl->ntile[level] < w.cap_tile ? w.ctl->ntile[level] : w.cap_tile;
+    const u64 *src = (level & 1) ? w.C : w.B;
+    const u32 cp = (u32)(lane & (COPIES - 1)) * 256u;
+    for (u32 t = blockIdx.x; t < nt; t += gridDim.x) {
+        const TileRef ref = w.tiles[set][t];
+        const Seg sg = w.segs[set][ref.seg];
+        const u32 k0 = ref.k * TILE;
+        const u32 m = sg.size - k0 < (u32)TILE ? sg.size - k0 : (u32)TILE;
+        for (int i = tid; i < 256 * COPIES; i += WG) {
+            lc[i] = 0;
+            lor[i] = 0;
+            lnor[i] = 0;
+        }
+        __syncthreads();
+        const u64 *p = src + sg.off + k0;
+        u64 k[ITEMS];
+#pragma unroll
+        for (int q = 0; q < ITEMS; ++q) {
+            const u32 j = q * WG + tid;
+            k[q] = j < m ? p[j] : 0ull;
+        }
+#pragma unroll
+        for (int q = 0; q < ITEMS; ++q) {
+            const u32 j = q * WG + tid;
+            const bool valid = j < m;
+            const u32 slot = cp + ((u32)(k[q] >> sg.shift) & 255u);
+            // lanes holding the first pending lane's KEY are counted by that lane (one repeated value is what
+            // fills most large bins); the others count for themselves, spread over COPIES copies
+            u64 rem = __ballot(valid);
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                if (rem == 0) break;
+                const int leader = __ffsll((long long)rem) - 1;
+                const u64 key0 = __shfl(k[q], leader);
+                const u64 same = __ballot(valid && k[q] == key0) & rem;
+                if (lane == leader) {
+                    atomicAdd(&lc[slot], (u32)__popcll(same));
+                    atomicOr(&lor[slot], key0);
+                    atomicOr(&lnor[slot], ~key0);
+                }
+                rem &= ~same;
+            }
+            if ((rem >> lane) & 1ull) {
+                atomicAdd(&lc[slot], 1u);
+                atomicOr(&lor[slot], k[q]);
+                atomicOr(&lnor[slot], ~k[q]);
+            }
+        }
+        __syncthreads();
+        if (tid < 256) {
+            u32 c = 0;
+            u64 a = 0, b = 0;
+#pragma unroll
+            for (int i = 0; i < COPIES; ++i) {
+                c += lc[i * 256 + tid];
+                a |= lor[i * 256 + tid];
+                b |= lnor[i * 256 + tid];
+            }
+            if (c && !(w.exp & 4u)) {
+                HistRow *row = &w.rows[set][ref.seg];
+                atomicAdd(&row->cnt[tid], c);
+                atomicOr(&row->orv[tid], a);
+                atomicOr(&row->norv[tid], b);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+struct PlanLds {
+    u32 cls[256], ccnt[256], cshift[256], aux[256];
+    u32 pk_off[256], pk_size[256];
+    u32 bigid[256];
+    u32 npk, nchunk, nbig, ntl;
+    u32 ft_base, seg_base, tile_base, ok;
+};
+
+// Decide what becomes of every bin of one segment (run by ONE workgroup per segment; `coff` = the bins'
+// offsets inside the segment): finish tiles, or segments and tiles of the next level.
+__device__ void plan_segment(const Ws &w, int level, u32 seg_off, u32 shift, const HistRow *row, const u32 *coff,
+                             u32 dst_id, PlanLds &pl) {
+    const int tid = threadIdx.x;
+    const int next = (level + 1) & 1;
+    if (tid < 256) {
+        const u32 c = row->cnt[tid];
+        const u64 o = row->orv[tid], no = row->norv[tid];
+        const bool known = (o | no) != 0;
+        const u64 diff = o ^ ~no;
+        u32 cls = 0, csh = 0;  // 0 empty, 1 small, 2 large and all equal, 3 large
+        if (c) {
+            if ((known && diff == 0) || shift == 0) cls = c <= (u32)CAP ? 1u : 2u;
+            else if (c <= (u32)CAP) cls = 1u;
+            else {
+                cls = 3u;
+                if (known) {
+                    const int hb = 63 - __builtin_clzll(diff);
+                    csh = hb > 7 ? (u32)(hb - 7) : 0u;
+                } else {
+                    csh = shift - 8;  // (root level only: shift is 56 or 48)
+                }
+            }
+        }
+        pl.cls[tid] = cls;
+        pl.ccnt[tid] = c;
+        pl.cshift[tid] = csh;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        u32 npk = 0, nchunk = 0, nbig = 0, ntl = 0, run_off = 0, run_size = 0;
+        for (int b = 0; b < 256; ++b) {
+            const u32 cls = pl.cls[b], c = pl.ccnt[b];
+            if (cls == 1u) {
+                if (run_size && run_size + c > (u32)CAP) {
+                    pl.pk_off[npk] = run_off;
+                    pl.pk_size[npk++] = run_size;
+                    run_size = 0;
+                }
+                if (!run_size) run_off = coff[b];
+                run_size += c;
+            } else if (cls >= 2u) {
+                if (run_size) {
+                    pl.pk_off[npk] = run_off;
+                    pl.pk_size[npk++] = run_size;
+                    run_size = 0;
+                }
+                if (cls == 2u) {
+                    pl.aux[b] = nchunk;  // first chunk tile of the bin
+                    nchunk += (c + CAP - 1) / CAP;
+                } else {
+                    pl.aux[b] = ntl;     // first tile of the new segment
+                    pl.bigid[nbig++] = b;
+                    ntl += (c + TILE - 1) / TILE;
+                }
+            }
+        }
+        if (run_size) {
+            pl.pk_off[npk] = run_off;
+            pl.pk_size[npk++] = run_size;
+        }
+        pl.npk = npk;
+        pl.nchunk = nchunk;
+        pl.nbig = nbig;
+        pl.ntl = ntl;
+        u32 ok = 1;
+        pl.ft_base = atomicAdd(&w.ctl->nft, npk + nchunk);
+        if ((u64)pl.ft_base + npk + nchunk > (u64)w.cap_ft) {
+            atomicOr(&w.ctl->err, ERR_FT);
+            ok = 0;
+        }
+        pl.seg_base = pl.tile_base = 0;
+        if (nbig) {
+            if (level + 1 >= MAX_LEVELS) {  // cannot happen: the digit moves down by >= 8 bits per level
+                atomicOr(&w.ctl->err, ERR_LEVEL);
+                ok = 0;
+            } else {
+                pl.seg_base = atomicAdd(&w.ctl->nseg[level + 1], nbig);
+                pl.tile_base = atomicAdd(&w.ctl->ntile[level + 1], ntl);
+                if ((u64)pl.seg_base + nbig > (u64)w.cap_seg) {
+                    atomicOr(&w.ctl->err, ERR_SEG);
+                    ok = 0;
+                }
+                if ((u64)pl.tile_base + ntl > (u64)w.cap_tile) {
+                    atomicOr(&w.ctl->err, ERR_TILE);
+                    ok = 0;
+                }
+                atomicMax(&w.ctl->levels_used, (u32)(level + 2));
+                atomicAdd(&w.ctl->segs_total, nbig);
+            }
+        }
+        pl.ok = ok;
+    }
+    __syncthreads();
+    if (!pl.ok) return;  // (the error word is set: the result will be poisoned; write nothing out of range)
+    for (u32 i = tid; i < pl.npk; i += WG) {
+        FTile f;
+        f.off = seg_off + pl.pk_off[i];
+        f.size = pl.pk_size[i];
+        f.src = dst_id;
+        f.pad = 0;
+        w.ft[pl.ft_base + i] = f;
+    }
+    if (tid < 256 && pl.cls[tid] == 2u) {
+        const u32 c = pl.ccnt[tid];
+        const u32 nch = (c + CAP - 1) / CAP;
+        for (u32 q = 0; q < nch; ++q) {
+            FTile f;
+            f.off = seg_off + coff[tid] + q * CAP;
+            f.size = c - q * CAP < (u32)CAP ? c - q * CAP : (u32)CAP;
+            f.src = dst_id;
+            f.pad = 0;
+            w.ft[pl.ft_base + pl.npk + pl.aux[tid] + q] = f;
+        }
+    }
+    for (u32 i = tid; i < pl.nbig; i += WG) {
+        const u32 b = pl.bigid[i];
+        Seg s;
+        s.off = seg_off + coff[b];
+        s.size = pl.ccnt[b];
+        s.shift = pl.cshift[b];
+        s.pad = 0;
+        w.segs[next][pl.seg_base + i] = s;
+        const u32 nt = (s.size + TILE - 1) / TILE;
+        TileRef *tr = w.tiles[next] + pl.tile_base + pl.aux[b];
+        for (u32 k = 0; k < nt; ++k) {
+            TileRef r;
+            r.seg = pl.seg_base + i;
+            r.k = k;
+            tr[k] = r;
+        }
+    }
+    // clean histogram rows for the new segments
+    for (u32 i = 0; i < pl.nbig; ++i) {
+        u32 *p = (u32 *)&w.rows[next][pl.seg_base + i];
+        for (u32 j = tid; j < sizeof(HistRow) / 4; j += WG) p[j] = 0;
+    }
+}
+
+template <bool ROOT>
+__global__ void __launch_bounds__(WG) k_scatter(Ws w, int level) {
+    __shared__ u64 stage[TILE];
+    __shared__ u32 lcnt[256 * COPIES], lstart[256 * COPIES], gbase[256], coff[256], csize[256];
+    __shared__ u32 wtot[NWAVE];
+    __shared__ PlanLds pl;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int set = level & 1;
+    const u32 H = w.ctl->n_heavy;
+    const u64 *src = ROOT ? (H ? (const u64 *)w.B : w.in) : ((level & 1) ? (const u64 *)w.C : (const u64 *)w.B);
+    u64 *dst = ROOT ? w.C : ((level & 1) ? w.B : w.C);
+    const u32 dst_id = ROOT ? (u32)SRC_C : ((level & 1) ? (u32)SRC_B : (u32)SRC_C);
+
+    u32 cur_seg = 0xFFFFFFFFu;
+    Seg sg;
+    sg.off = sg.size = sg.shift = sg.pad = 0;
+    HistRow *row = nullptr;
+    u32 n_items;  // tiles (levels >= 1) or regions (root)
+    if (ROOT) {
+        const u32 n_tail = w.ctl->n_tail;
+        if (n_tail == 0) return;
+        if (H == 0 && n_tail <= (u32)CAP) {  // the whole input is one finish tile, read where it lies
+            if (blockIdx.x == 0 && tid == 0) {
+                FTile f;
+                f.off = 0;
+                f.size = n_tail;
+                f.src = SRC_IN;
+                f.pad = 0;
+                w.ft[0] = f;  // cap_ft >= 1
+                w.ctl->nft = 1;
+            }
+            return;
+        }
+        const u64 diff = w.ctl->or_all ^ ~w.ctl->nor_all;
+        sg.size = n_tail;
+        sg.shift = (diff >> 56) ? 56u : 48u;
+        row = &w.root[sg.shift == 56u ? 1 : 0];
+        n_items = w.regions;
+        u32 tot;
+        const u32 v = tid < 256 ? row->cnt[tid] : 0u;
+        const u32 ex = wg_excl_scan(v, wtot, tot);
+        if (tid < 256) {
+            coff[tid] = ex;
+            csize[tid] = v;
+        }
+        __syncthreads();
+        if (blockIdx.x == 0) {
+            plan_segment(w, 0, 0u, sg.shift, row, coff, dst_id, pl);
+            if (tid == 0) atomicMax(&w.ctl->levels_used, 1u);
+        }
+    } else {
+        if (w.ctl->err) return;
+        n_items = w.ctl->ntile[level] < w.cap_tile ? w.ctl->ntile[level] : w.cap_tile;
+    }
+    for (u32 it = blockIdx.x; it < n_items; it += gridDim.x) {
+        u32 tile_lo, tile_hi;  // key range of this item inside `src`, in steps of TILE
+        u64 base_in;
+        if (ROOT) {
+            base_in = (u64)it * REGION;
+            tile_lo = 0;
+            tile_hi = w.rcnt[it];
+        } else {
+            const TileRef ref = w.tiles[set][it];
+            if (ref.seg != cur_seg) {
+                cur_seg = ref.seg;
+                sg = w.segs[set][ref.seg];
+                row = &w.rows[set][ref.seg];
+                u32 tot;
+                const u32 v = tid < 256 ? row->cnt[tid] : 0u;
+                const u32 ex = wg_excl_scan(v, wtot, tot);
+                __syncthreads();  // (coff may still be read by the previous tile's write-out)
+                if (tid < 256) {
+                    coff[tid] = ex;
+                    csize[tid] = v;
+                }
+                __syncthreads();
+            }
+            if (ref.k == 0) plan_segment(w, level, sg.off, sg.shift, row, coff, dst_id, pl);
+            base_in = sg.off;
+            tile_lo = ref.k * TILE;
+            tile_hi = sg.size - tile_lo < (u32)TILE ? sg.size : tile_lo + TILE;
+        }
+        for (u32 k0 = tile_lo; k0 < tile_hi; k0 += TILE) {
+            const u32 m = tile_hi - k0 < (u32)TILE ? tile_hi - k0 : (u32)TILE;
+            for (int i = tid; i < 256 * COPIES; i += WG) lcnt[i] = 0;
+            __syncthreads();
+            u64 k[ITEMS];
+            u32 rk[ITEMS], sl[ITEMS];
+            const u64 *p = src + base_in + k0;
+#pragma unroll
+            for (int q = 0; q < ITEMS; ++q) {
+                const u32 j = q * WG + tid;
+                k[q] = j < m ? p[j] : 0ull;
+            }
+#pragma unroll
+            for (int q = 0; q < ITEMS; ++q) {
+                const u32 j = q * WG + tid;
+                sl[q] = (((u32)(k[q] >> sg.shift) & 255u) << 2) + (u32)(lane & (COPIES - 1));  // bin-major
+                rk[q] = lds_rank_add(lcnt, sl[q], k[q], j < m, lane);
+            }
+            __syncthreads();
+            {
+                // exclusive scan over the 256 x COPIES slots (bin-major): where each slot starts in `stage`
+                static_assert(256 * COPIES == 2 * WG && COPIES == 4, "two slots per thread, four per bin");
+                const u32 c0 = lcnt[2 * tid], c1 = lcnt[2 * tid + 1];
+                u32 tot;
+                const u32 ex = wg_excl_scan(c0 + c1, wtot, tot);
+                lstart[2 * tid] = ex;
+                lstart[2 * tid + 1] = ex + c0;
+            }
+            __syncthreads();
+            if (tid < 256) {
+                const u32 v = lcnt[4 * tid] + lcnt[4 * tid + 1] + lcnt[4 * tid + 2] + lcnt[4 * tid + 3];
+                gbase[tid] = (v && !(w.exp & 1u)) ? atomicAdd(&row->cur[tid], v) : 0u;  // the bin's next free place: order is free
+            }
+#pragma unroll
+            for (int q = 0; q < ITEMS; ++q) {
+                const u32 j = q * WG + tid;
+                if (j < m) stage[lstart[sl[q]] + rk[q]] = k[q];
+            }
+            __syncthreads();
+            for (u32 j = tid; j < m; j += WG) {
+                const u64 key = stage[j];
+                const u32 d = (u32)(key >> sg.shift) & 255u;
+                const u32 in_bin = gbase[d] + (j - lstart[4 * d]);
+                // (counts that do not match the keys -- a caller overwriting them mid-sort -- must end as a
+                // poisoned result, never as a store outside the bin)
+                if (w.exp & 16u) continue;
+                if (in_bin < csize[d]) dst[(u64)sg.off + coff[d] + in_bin] = key;
+                else atomicOr(&w.ctl->err, ERR_RANGE);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---- finish tiles ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WG) k_finish(Ws w) {
+    __shared__ u64 stage[CAP];
+    __shared__ u32 start[BINS + 1];
+    __shared__ u64 hv[H_MAX];
+    __shared__ u32 hp[H_MAX + 1];    // copies of the heavy values below index i
+    __shared__ u32 gapl[H_MAX + 1];
+    __shared__ u32 wtot[NWAVE];
+    __shared__ u64 red[2 * NWAVE];
+    __shared__ u32 large[2 * (CAP / SMALL_GROUP)];
+    __shared__ u32 nlarge;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const u32 H = w.ctl->n_heavy;
+    if (w.ctl->err) return;  // a table overflowed in an earlier kernel: the tile list is not to be trusted
+    const u32 nft = w.ctl->nft < w.cap_ft ? w.ctl->nft : w.cap_ft;
+    if (blockIdx.x >= nft) return;
+    // heavy values and the prefix sums of their copies
+    {
+        u32 c[2];
+        u32 s = 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const u32 i = tid * 2 + q;
+            c[q] = i < H ? w.hcnt[i] : 0u;
+            if (i < H) hv[i] = w.heavy[i];
+            s += c[q];
+        }
+        u32 tot;
+        u32 ex = wg_excl_scan(s, wtot, tot);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const u32 i = tid * 2 + q;
+            if (i <= H) hp[i] = ex;
+            ex += c[q];
+        }
+        if (tid == 0) hp[H] = tot;
+        for (u32 i = tid; i <= (u32)H_MAX; i += WG) gapl[i] = 0;
+    }
+    __syncthreads();
+    auto heavy_below = [&](u64 key, u32 lo, u32 hi) {  // values of hv[lo..hi) that are < key, + lo
+        while (lo < hi) {
+            const u32 mid = (lo + hi) >> 1;
+            if (hv[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    for (u32 t = blockIdx.x; t < nft; t += gridDim.x) {
+        const FTile f = w.ft[t];
+        const u32 m = f.size < (u32)CAP ? f.size : (u32)CAP;
+        const u64 *src = (f.src == SRC_IN ? w.in : (f.src == SRC_B ? (const u64 *)w.B : (const u64 *)w.C)) + f.off;
+        u64 *out = w.A + f.off;
+        const u64 room = (u64)w.n - f.off;  // a final index is < n; checked at every store
+        u64 k[ITEMS];
+        u64 mn = EMPTY, mx = 0;
+#pragma unroll
+        for (int q = 0; q < ITEMS; ++q) {
+            const u32 j = q * WG + tid;
+            k[q] = j < m ? src[j] : 0ull;
+            if (j < m) {
+                mn = k[q] < mn ? k[q] : mn;
+                mx = k[q] > mx ? k[q] : mx;
+            }
+        }
+        mn = wave_min(mn);
+        mx = wave_max(mx);
+        if (lane == 0) {
+            red[wid] = mn;
+            red[NWAVE + wid] = mx;
+        }
+        if (tid == 0) nlarge = 0;
+        __syncthreads();
+        mn = red[0];
+        mx = red[NWAVE];
+#pragma unroll
+        for (int i = 1; i < NWAVE; ++i) {
+            mn = red[i] < mn ? red[i] : mn;
+            mx = red[NWAVE + i] > mx ? red[NWAVE + i] : mx;
+        }
+        const u32 idx_lo = heavy_below(mn, 0, H), idx_hi = heavy_below(mx, idx_lo, H);
+        if (mn == mx) {  // one value: copy it to its place
+            const u32 shiftv = hp[idx_lo];
+#pragma unroll
+            for (int q = 0; q < ITEMS; ++q) {
+                const u32 j = q * WG + tid;
+                if (j < m) {
+                    if ((u64)j + shiftv < room) out[j + shiftv] = k[q]; else atomicOr(&w.ctl->err, ERR_RANGE);
+                }
+            }
+            __syncthreads();
+            if (tid == 0) gapl[idx_lo] += m;
+            continue;
+        }
+        // linear buckets over [mn, mx]: (key - mn) >> sh < BINS
+        const u64 range = mx - mn;
+        const int bl = 64 - __builtin_clzll(range);
+        const int sh = bl > 12 ? bl - 12 : 0;
+        for (int i = tid; i <= BINS; i += WG) start[i] = 0;
+        __syncthreads();
+        u32 rk[ITEMS];
+#pragma unroll
+        for (int q = 0; q < ITEMS; ++q) {
+            const u32 j = q * WG + tid;
+            u32 slot = (u32)((k[q] - mn) >> sh);
+            rk[q] = lds_rank_add(start, slot, k[q], j < m, lane);
+        }
+        __syncthreads();
+        {
+            u32 c[BINS / WG];
+            u32 s = 0;
+#pragma unroll
+            for (int q = 0; q < BINS / WG; ++q) {
+                c[q] = start[tid * (BINS / WG) + q];
+                s += c[q];
+            }
+            u32 tot;
+            u32 ex = wg_excl_scan(s, wtot, tot);
+#pragma unroll
+            for (int q = 0; q < BINS / WG; ++q) {
+                start[tid * (BINS / WG) + q] = ex;
+                ex += c[q];
+            }
+            if (tid == 0) start[BINS] = m;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < ITEMS; ++q) {
+            const u32 j = q * WG + tid;
+            if (j < m) stage[start[(u32)((k[q] - mn) >> sh)] + rk[q]] = k[q];
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int q = 0; q < ITEMS; ++q) {
+            const u32 j = q * WG + tid;
+            if (j >= m) break;
+            const u64 key = stage[j];
+            const u32 d = (u32)((key - mn) >> sh);
+            const u32 s = start[d], e = start[d + 1], g = e - s;
+            u32 pos = j;
+            if (g > (u32)SMALL_GROUP) {
+                if (j == s) {
+                    const u32 li = atomicAdd(&nlarge, 1u);
+                    large[2 * li] = s;
+                    large[2 * li + 1] = g;
+                }
+                continue;
+            }
+            if (g > 1) {
+                u32 r = 0;
+                for (u32 i = s; i < e; ++i) {
+                    const u64 o2 = stage[i];
+                    r += (o2 < key || (o2 == key && i < j)) ? 1u : 0u;
+                }
+                pos = s + r;
+            }
+            const u32 hidx = idx_lo == idx_hi ? idx_lo : heavy_below(key, idx_lo, idx_hi);
+            const u64 at = (u64)pos + hp[hidx];
+            if (at < room) out[at] = key; else atomicOr(&w.ctl->err, ERR_RANGE);
+            if (idx_lo != idx_hi) atomicAdd(&gapl[hidx], 1u);
+        }
+        __syncthreads();
+        // large buckets: a wave walks the bucket's distinct values in ascending order (a repeated value and
+        // a few neighbours, typically); the bucket's keys all lie within range / BINS of each other
+        const u32 nl = nlarge;
+        for (u32 li = wid; li < nl; li += NWAVE) {
+            const u32 s = large[2 * li], g = large[2 * li + 1];
+            u32 placed = 0;
+            u64 last = 0;
+            bool have_last = false;
+            while (placed < g) {
+                u64 cand = EMPTY;
+                for (u32 i = lane; i < g; i += 64) {
+                    const u64 v = stage[s + i];
+                    if ((!have_last || v > last) && v < cand) cand = v;
+                }
+                cand = wave_min(cand);
+                u32 c = 0;
+                for (u32 i = lane; i < g; i += 64) c += stage[s + i] == cand ? 1u : 0u;
+                c = wave_sum(c);
+                if (c == 0) break;  // (cannot happen; guards the loop)
+                const u32 hidx = idx_lo == idx_hi ? idx_lo : heavy_below(cand, idx_lo, idx_hi);
+                const u64 at0 = (u64)s + placed + hp[hidx];
+                for (u32 i = lane; i < c; i += 64) {
+                    if (at0 + i < room) out[at0 + i] = cand; else atomicOr(&w.ctl->err, ERR_RANGE);
+                }
+                if (lane == 0 && idx_lo != idx_hi) atomicAdd(&gapl[hidx], c);
+                placed += c;
+                last = cand;
+                have_last = true;
+            }
+        }
+        __syncthreads();
+        // (no heavy value inside the tile's range: all its keys have the same number of heavy values below)
+        if (idx_lo == idx_hi && tid == 0) gapl[idx_lo] += m;
+    }
+    __syncthreads();
+    for (u32 i = tid; i <= H; i += WG)
+        if (gapl[i]) atomicAdd(&w.gap[i], gapl[i]);
+}
+
+// ---- the runs of the heavy values -----------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_fill(Ws w) {
+    constexpr int CHUNK = 4096;
+    __shared__ u64 hv[H_MAX];
+    __shared__ u32 hp[H_MAX + 1];    // copies of heavy values below index i
+    __shared__ u32 st[H_MAX];        // final index of the first copy of heavy value i
+    __shared__ u32 tmp[H_MAX + 1];
+    const int tid = threadIdx.x;
+    const u32 H = w.ctl->n_heavy;
+    if (H == 0 || w.ctl->err) return;
+    // (<= 1024 values: a serial prefix by one thread per array is a few microseconds, once per workgroup)
+    for (u32 i = tid; i < H; i += 256) {
+        hv[i] = w.heavy[i];
+        tmp[i] = w.hcnt[i];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        u32 run = 0;
+        for (u32 i = 0; i < H; ++i) {
+            hp[i] = run;
+            run += tmp[i];
+        }
+        hp[H] = run;
+    }
+    __syncthreads();
+    const u32 total = hp[H];
+    if ((u64)blockIdx.x * CHUNK >= total) return;
+    for (u32 i = tid; i <= H; i += 256) tmp[i] = w.gap[i];
+    __syncthreads();
+    if (tid == 0) {
+        u32 below = 0;
+        for (u32 i = 0; i < H; ++i) {
+            below += tmp[i];  // tail keys with at most i heavy values below them ARE below heavy value i
+            st[i] = hp[i] + below;
+        }
+    }
+    __syncthreads();
+    auto run_of = [&](u64 x) {  // last i with hp[i] <= x
+        u32 lo = 0, hi = H;
+        while (hi - lo > 1) {
+            const u32 mid = (lo + hi) >> 1;
+            if (hp[mid] <= x) lo = mid; else hi = mid;
+        }
+        return lo;
+    };
+    for (u64 x0 = (u64)blockIdx.x * CHUNK; x0 < total; x0 += (u64)gridDim.x * CHUNK) {
+        const u64 x1 = x0 + CHUNK < total ? x0 + CHUNK : total;  // this chunk: copies x0 .. x1-1 of all heavy copies
+        const u32 j0 = run_of(x0), j1 = run_of(x1 - 1);
+        if (j0 == j1) {  // (the common case: runs are long)
+            const u64 v = hv[j0];
+            const u64 at0 = (u64)st[j0] + (x0 - hp[j0]);
+            for (u32 i = tid; i < (u32)(x1 - x0); i += 256) {
+                if (at0 + i < w.n) w.A[at0 + i] = v; else atomicOr(&w.ctl->err, ERR_RANGE);
+            }
+        } else {
+            for (u64 x = x0 + tid; x < x1; x += 256) {
+                u32 lo = j0, hi = j1 + 1;
+                while (hi - lo > 1) {
+                    const u32 mid = (lo + hi) >> 1;
+                    if (hp[mid] <= x) lo = mid; else hi = mid;
+                }
+                const u64 at = (u64)st[lo] + (x - hp[lo]);
+                if (at < w.n) w.A[at] = hv[lo]; else atomicOr(&w.ctl->err, ERR_RANGE);
+            }
+        }
+    }
+}
+
+__global__ void k_force_error(Ctl *ctl) { atomicOr(&ctl->err, ERR_DEBUG); }
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Layout {
+    size_t B, C, ctl, heavy, hcnt, gap, hotv, hoti, root, rcnt, segs[2], rows[2], tiles[2], ft, end;
+    u32 regions, cap_seg, cap_tile, cap_ft;
+    size_t clear_from, clear_bytes;
+};
+
+Layout layout_for(u64 n) {
+    Layout L;
+    L.regions = (u32)((n + REGION - 1) / REGION);
+    L.cap_seg = (u32)(n / CAP + 2);
+    L.cap_tile = (u32)(n / TILE + L.cap_seg + 2);
+    L.cap_ft = (u32)(3 * (n / CAP) + 3 * (u64)MAX_LEVELS * (n / CAP + 2) + 64);
+    size_t p = 0;
+    L.B = p; p += align256(n * sizeof(u64));
+    L.C = p; p += align256(n * sizeof(u64));
+    L.clear_from = p;
+    L.ctl = p; p += align256(sizeof(Ctl));
+    L.heavy = p; p += align256(H_MAX * sizeof(u64));
+    L.hcnt = p; p += align256(H_MAX * sizeof(u32));
+    L.gap = p; p += align256((H_MAX + 1) * sizeof(u32));
+    L.hotv = p; p += align256(HOT * sizeof(u64));
+    L.hoti = p; p += align256(HOT * sizeof(u32));
+    L.root = p; p += align256(2 * sizeof(HistRow));
+    L.clear_bytes = p - L.clear_from;
+    L.rcnt = p; p += align256((size_t)L.regions * sizeof(u32));
+    for (int i = 0; i < 2; ++i) {
+        L.segs[i] = p; p += align256((size_t)L.cap_seg * sizeof(Seg));
+        L.rows[i] = p; p += align256((size_t)L.cap_seg * sizeof(HistRow));
+        L.tiles[i] = p; p += align256((size_t)L.cap_tile * sizeof(TileRef));
+    }
+    L.ft = p; p += align256((size_t)L.cap_ft * sizeof(FTile));
+    L.end = p;
+    return L;
+}
+
+}  // namespace
+
+size_t mc_sort_workspace_bytes(uint64_t n) { return layout_for(n).end; }
+
+int mc_sort_keys(const uint64_t *in, uint64_t n, uint64_t *out, void *workspace, size_t workspace_bytes,
+                 uint32_t **err_word_out, int debug_fail, hipStream_t s) {
+    const Layout L = layout_for(n);
+    if (workspace_bytes < L.end) {
+        mc_set_error("mc_sort_keys: workspace of %zu bytes, need %zu", workspace_bytes, L.end);
+        return MC_ERR_WORKSPACE;
+    }
+    char *base = (char *)workspace;
+    Ws w;
+    w.ctl = (Ctl *)(base + L.ctl);
+    w.heavy = (u64 *)(base + L.heavy);
+    w.hcnt = (u32 *)(base + L.hcnt);
+    w.gap = (u32 *)(base + L.gap);
+    w.hotv = (u64 *)(base + L.hotv);
+    w.hoti = (u32 *)(base + L.hoti);
+    w.root = (HistRow *)(base + L.root);
+    w.rcnt = (u32 *)(base + L.rcnt);
+    for (int i = 0; i < 2; ++i) {
+        w.segs[i] = (Seg *)(base + L.segs[i]);
+        w.rows[i] = (HistRow *)(base + L.rows[i]);
+        w.tiles[i] = (TileRef *)(base + L.tiles[i]);
+    }
+    w.ft = (FTile *)(base + L.ft);
+    w.in = (const u64 *)in;
+    w.A = (u64 *)out;
+    w.B = (u64 *)(base + L.B);
+    w.C = (u64 *)(base + L.C);
+    w.n = (u32)n;
+    w.regions = L.regions;
+    w.cap_seg = L.cap_seg;
+    w.cap_tile = L.cap_tile;
+    w.cap_ft = L.cap_ft;
+    w.exp = getenv("MC_SORT_EXP") ? (u32)atoi(getenv("MC_SORT_EXP")) : 0u;
+    if (debug_fail) w.cap_ft = 1;  // the first plan overflows the finish-tile table: the failure path, on demand
+    if (err_word_out) *err_word_out = &w.ctl->err;
+
+    HIP_TRY(hipMemsetAsync(base + L.clear_from, 0, L.clear_bytes, s));
+    const u32 g_region = L.regions < 2048u ? L.regions : 2048u;
+    hipLaunchKernelGGL(k_sniff, dim3(1), dim3(SNIFF_THREADS), 0, s, w);
+    hipLaunchKernelGGL(k_strip, dim3(g_region), dim3(WG), 0, s, w);
+    hipLaunchKernelGGL(k_scatter<true>, dim3(g_region), dim3(WG), 0, s, w, 0);
+    const u32 max_tiles = (u32)(n / TILE + 1);
+    for (int level = 1; level < MAX_LEVELS; ++level) {
+        // deeper levels hold less and less (a bin must exceed CAP keys AND not be one repeated value to get there)
+        const u32 want = level == 1 ? 2048u : level == 2 ? 1024u : 256u;
+        const u32 g = max_tiles < want ? max_tiles : want;
+        if (n <= (u64)CAP) break;  // one finish tile, planned by the root
+        hipLaunchKernelGGL(k_count, dim3(g), dim3(WG), 0, s, w, level);
+        hipLaunchKernelGGL(k_scatter<false>, dim3(g), dim3(WG), 0, s, w, level);
+    }
+    if (debug_fail) hipLaunchKernelGGL(k_force_error, dim3(1), dim3(1), 0, s, w.ctl);
+    const u32 g_ft = L.cap_ft < 1024u ? L.cap_ft : 1024u;
+    hipLaunchKernelGGL(k_finish, dim3(g_ft), dim3(WG), 0, s, w);
+    hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, s, w);
+    HIP_TRY(hipGetLastError());
+    return MC_OK;
+}
+
+int mc_sort_info(const void *workspace, uint64_t n, uint64_t info[8], hipStream_t s) {
+    const Layout L = layout_for(n);
+    Ctl c;
+    HIP_TRY(hipMemcpyAsync(&c, (const char *)workspace + L.ctl, sizeof c, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    info[0] = c.err;
+    info[1] = c.n_heavy;
+    info[2] = c.n_tail;
+    info[3] = c.levels_used;
+    info[4] = c.nft;
+    info[5] = c.segs_total;
+    info[6] = info[7] = 0;
+    return MC_OK;
+}

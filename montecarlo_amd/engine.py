@@ -192,6 +192,17 @@ class DeviceRank:
                                           C.c_void_p(torch.cuda.current_stream(self.tdev).cuda_stream)))
             self._ws = ws
 
+    def check(self) -> dict:
+        """Synchronise and read the build's status (mc_rank_check): raises if the sort failed on the device
+        (positions are NaN then); returns the sort's counters."""
+        info = (C.c_uint64 * 8)()
+        with torch.cuda.device(self.tdev):
+            rc = nv.lib.mc_rank_check(_vp(self._ws), self.n,
+                                      C.c_void_p(torch.cuda.current_stream(self.tdev).cuda_stream), info)
+        out = dict(zip(("error", "heavy_values", "tail_keys", "levels", "finish_tiles", "segments"), list(info)))
+        nv.check(rc)
+        return out
+
     def query(self, x: torch.Tensor, out_pos: torch.Tensor = None, out_cnt: torch.Tensor = None):
         """(pos, cnt): cnt = bisect_right(sorted, x), pos = positions[cnt-1] (0.0 when cnt == 0)."""
         assert x.is_cuda and x.dtype == torch.float64 and x.is_contiguous()

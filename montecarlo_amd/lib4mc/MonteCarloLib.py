@@ -154,7 +154,7 @@ def _format_native(gc, cols=None) -> "str | None":
         return None
     if not (numpy.isfinite(mlp).all() and numpy.isfinite(ratio).all()):
         return None                                            # (C prints a NaN's sign, Python does not)
-    if float(numpy.abs(mlp).max()) >= 1e15 or float(numpy.abs(ratio).max()) >= 1e15:
+    if float(numpy.abs(mlp).max()) >= 1e18 or float(numpy.abs(ratio).max()) >= 1e9:
         return None                                            # (wider than the native writer's 120 characters)
     mlp, apps, rank, crk, ratio = (numpy.ascontiguousarray(x) for x in (mlp, apps, rank, crk, ratio))
     out = numpy.empty(len(blob) + 120 * n, dtype=numpy.uint8)           # (not zero-filled)

@@ -53,10 +53,9 @@ constexpr int TILE = 4096;         // keys per count / scatter tile
 constexpr int WG = 512;            // threads of the strip / count / scatter / finish workgroups
 constexpr int ITEMS = TILE / WG;   // keys per lane and tile
 constexpr int NWAVE = WG / 64;
-constexpr int REGION = 16384;      // keys per strip region (its tail is stored at the region's own offset)
+constexpr int REGION = 8192;       // keys per strip region (its tail is stored at the region's own offset)
 constexpr int SNIFF_S = 8192, SNIFF_SLOTS = 12288, SNIFF_MIN = 4, SNIFF_THREADS = 1024;
 constexpr int H_MAX = 1024, HSET = 2048;
-constexpr int HOT = 8;             // heavy values compared against directly, lane-private counters (no LDS at all)
 constexpr int COPIES = 4;          // lane-sliced copies of LDS histograms: lanes l, l+4, ... share one
 constexpr int MAX_LEVELS = 8;      // 64 bits / 8
 constexpr int BINS = 4096;         // buckets of a finish tile
@@ -99,8 +98,6 @@ struct Ws {
     u64 *heavy;      // [H_MAX] sorted heavy values
     u32 *hcnt;       // [H_MAX] their copies
     u32 *gap;        // [H_MAX + 1] tail keys with exactly g heavy values below them
-    u64 *hotv;       // [HOT] the heavy values seen most often in the sample (EMPTY: none) ...
-    u32 *hoti;       // [HOT] ... and their indices in `heavy`
     HistRow *root;   // [2]: digit at bits 48..55, digit at bits 56..63 (tail keys)
     u32 *rcnt;       // [regions] tail keys of each region
     Seg *segs[2];
@@ -111,7 +108,6 @@ struct Ws {
     u64 *A, *B, *C;
     u32 n, regions;
     u32 cap_seg, cap_tile, cap_ft;
-    u32 exp;  // experiment switches (MC_SORT_EXP, development only; results are WRONG when set)
 };
 
 __device__ __forceinline__ u32 hset_hash(u64 k) { return (u32)((k * 0x9E3779B97F4A7C15ull) >> 40); }
@@ -166,43 +162,14 @@ __device__ __forceinline__ u32 wave_sum(u32 v) {
     return v;
 }
 
-// LDS histogram add that returns the key's rank inside its (bin, copy) slot.  Sampled keys repeat, and lanes
-// that add to ONE LDS word in one instruction are served one after the other (measured: that, not memory, set
-// the pace of the first version of every kernel here).  So: the lanes whose KEY equals the first pending lane's
-// key are served by that lane with one add, into that lane's slot (twice); whoever is left adds for itself.
-// `slot` comes back as the slot the key was counted in.
-__device__ __forceinline__ u32 lds_rank_add(u32 *bins, u32 &slot, u64 key, bool valid, int lane) {
-    u32 rank = 0;
-    u64 rem = __ballot(valid);
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        if (rem == 0) break;  // (wave-uniform)
-        const int leader = __ffsll((long long)rem) - 1;
-        const u64 k0 = __shfl(key, leader);
-        const u32 s0 = __shfl(slot, leader);
-        const u64 same = __ballot(valid && key == k0) & rem;
-        u32 base = 0;
-        if (lane == leader) base = atomicAdd(&bins[s0], (u32)__popcll(same));
-        base = __shfl(base, leader);
-        if ((same >> lane) & 1ull) {
-            rank = base + (u32)__popcll(same & ((1ull << lane) - 1ull));
-            slot = s0;
-        }
-        rem &= ~same;
-    }
-    if ((rem >> lane) & 1ull) rank = atomicAdd(&bins[slot], 1u);
-    return rank;
-}
-
 // ---- heavy values -------------------------------------------------------------------------------------
 // One workgroup: SNIFF_S keys at a fixed stride into an LDS hash table (value, occurrences); the values seen
 // SNIFF_MIN times or more (at most H_MAX: the bar is raised until they fit) are the heavy values, written in
-// ascending order; the HOT most frequent of them are listed once more for k_strip's direct compares.
+// ascending order.
 __global__ void __launch_bounds__(SNIFF_THREADS) k_sniff(Ws w) {
     __shared__ u64 tk[SNIFF_SLOTS];
     __shared__ u32 tc[SNIFF_SLOTS / 2];  // two 16-bit counts per word
     __shared__ u64 list[H_MAX];
-    __shared__ u32 lcnt[H_MAX];
     __shared__ u32 nlist;
     const u32 n = w.n;
     const int tid = threadIdx.x;
@@ -248,46 +215,49 @@ __global__ void __launch_bounds__(SNIFF_THREADS) k_sniff(Ws w) {
         if (c >= bar) {
             const u32 p = atomicAdd(&nlist, 1u);
             list[p] = tk[i];  // p < H <= H_MAX
-            lcnt[p] = c;
         }
     }
     __syncthreads();
     for (u32 i = tid; i < H; i += SNIFF_THREADS) {  // the values are distinct: rank = position
         const u64 v = list[i];
-        const u32 c = lcnt[i];
-        u32 r = 0, by_count = 0;
-        for (u32 j = 0; j < H; ++j) {
-            r += list[j] < v ? 1u : 0u;
-            by_count += (lcnt[j] > c || (lcnt[j] == c && j < i)) ? 1u : 0u;
-        }
+        u32 r = 0;
+        for (u32 j = 0; j < H; ++j) r += list[j] < v ? 1u : 0u;
         w.heavy[r] = v;
-        if (by_count < (u32)HOT) {
-            w.hotv[by_count] = v;
-            w.hoti[by_count] = r;
-        }
     }
     if (tid == 0) w.ctl->n_heavy = H;
 }
 
 // ---- strip: count the copies of heavy values, compact the tail ------------------------------------------
+// Per tile of 8 keys a lane: all hash-table reads are issued together, the heavy keys are counted per table
+// SLOT (translated to the heavy value's index once per workgroup), the tail keys of the 8 rounds take their
+// places from ONE add per wave.  (The first version did each key's lookup, count and compaction one after the
+// other, ~10 dependent LDS round trips per key: 88 us; instruction count and LDS latency, not memory, set the pace.)
+__device__ __forceinline__ u32 strip_hash(u64 k) {
+    const u32 lo = (u32)k, hi = (u32)(k >> 32);
+    u32 x = lo ^ (hi * 0x9E3779B1u);
+    x ^= x >> 15;
+    return (x * 0x85EBCA6Bu) >> 21;  // 11 bits = HSET slots
+}
+
 __global__ void __launch_bounds__(WG) k_strip(Ws w) {
-    __shared__ u64 hk[HSET];
-    __shared__ u32 hi[HSET];
-    __shared__ u32 hc[H_MAX];
+    static_assert(HSET == 2048, "strip_hash yields 11 bits");
+    __shared__ u64 hk[HSET + 1];  // (+1: the pair read of the last slot)
+    __shared__ u32 hs[HSET];      // copies counted per slot
+    __shared__ u32 hi[HSET];      // slot -> index of the heavy value
     __shared__ u32 h48[256 * COPIES], h56[256];
     __shared__ u32 roff;
     __shared__ u64 red[2 * NWAVE];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const u32 H = w.ctl->n_heavy;
     const u32 n = w.n;
-    for (int i = tid; i < HSET; i += WG) hk[i] = EMPTY;
-    for (int i = tid; i < H_MAX; i += WG) hc[i] = 0;
+    for (int i = tid; i <= HSET; i += WG) hk[i] = EMPTY;
+    for (int i = tid; i < HSET; i += WG) hs[i] = 0;
     for (int i = tid; i < 256 * COPIES; i += WG) h48[i] = 0;
     if (tid < 256) h56[tid] = 0;
     __syncthreads();
     for (u32 i = tid; i < H; i += WG) {
         const u64 v = w.heavy[i];
-        u32 s = hset_hash(v) & (HSET - 1);
+        u32 s = strip_hash(v);
         for (;;) {  // H <= HSET / 2 distinct values
             const u64 old = atomicCAS(&hk[s], EMPTY, v);
             if (old == EMPTY) {
@@ -297,18 +267,11 @@ __global__ void __launch_bounds__(WG) k_strip(Ws w) {
             s = (s + 1) & (HSET - 1);
         }
     }
-    u64 hot[HOT];
-    u32 hotc[HOT];
-    const u32 nhot = H < (u32)HOT ? H : (u32)HOT;  // k_sniff filled hotv / hoti [0, nhot)
-#pragma unroll
-    for (int i = 0; i < HOT; ++i) {
-        hot[i] = (u32)i < nhot ? w.hotv[i] : 0ull;  // (uniform: scalar registers)
-        hotc[i] = 0;
-    }
     __syncthreads();
     u64 o = 0, no = 0;
     u32 tail_total = 0;  // (thread 0)
     const u32 cp = (u32)(lane & (COPIES - 1)) * 256u;
+    const u64 lt = (1ull << lane) - 1ull;
     for (u32 r = blockIdx.x; r < w.regions; r += gridDim.x) {
         const u64 lo = (u64)r * REGION;
         const u32 rn = (u32)(n - lo < (u64)REGION ? n - lo : (u64)REGION);
@@ -330,54 +293,99 @@ __global__ void __launch_bounds__(WG) k_strip(Ws w) {
                     nk[q] = j < rn ? w.in[lo + j] : EMPTY;
                 }
             }
+            u64 tmask[ITEMS];
+            u32 total = 0;
+            if (H) {
+                u32 s[ITEMS];
+                u64 a[ITEMS], b[ITEMS];
 #pragma unroll
-            for (int q = 0; q < ITEMS; ++q) {
-                const u32 j = c0 + q * WG + tid;
-                bool tail = j < rn;
-                if (tail && H) {
-                    bool is_hot = false;
+                for (int q = 0; q < ITEMS; ++q) {
+                    s[q] = strip_hash(k[q]);
+                    a[q] = hk[s[q]];
+                    b[q] = hk[s[q] + 1];
+                }
 #pragma unroll
-                    for (int i = 0; i < HOT; ++i) {
-                        const bool hit = (u32)i < nhot && k[q] == hot[i];
-                        hotc[i] += hit ? 1u : 0u;
-                        is_hot |= hit;
-                    }
-                    if (is_hot) {
-                        tail = false;
-                    } else if (!(w.exp & 8u)) {
-                        u32 s = hset_hash(k[q]) & (HSET - 1);
-                        for (;;) {
-                            const u64 t = hk[s];
-                            if (t == k[q]) {
-                                if (t != EMPTY) {  // (a key equal to the empty marker is never heavy)
-                                    atomicAdd(&hc[hi[s]], 1u);
-                                    tail = false;
+                for (int q = 0; q < ITEMS; ++q) {
+                    const bool valid = c0 + q * WG + tid < rn;
+                    bool tail = valid;
+                    if (valid && k[q] != EMPTY) {  // (a key equal to the empty marker is never heavy)
+                        if (a[q] == k[q]) {
+                            atomicAdd(&hs[s[q]], 1u);
+                            tail = false;
+                        } else if (a[q] != EMPTY) {
+                            if (b[q] == k[q] && s[q] + 1 < (u32)HSET) {
+                                atomicAdd(&hs[s[q] + 1], 1u);
+                                tail = false;
+                            } else if (b[q] != EMPTY || s[q] + 1 == (u32)HSET) {
+                                u32 t = (s[q] + 2) & (HSET - 1);  // (rare: a run of three or more taken slots)
+                                if (s[q] + 1 == (u32)HSET) t = 0;
+                                for (;;) {
+                                    const u64 v = hk[t];
+                                    if (v == k[q]) {
+                                        atomicAdd(&hs[t], 1u);
+                                        tail = false;
+                                        break;
+                                    }
+                                    if (v == EMPTY) break;
+                                    t = (t + 1) & (HSET - 1);
                                 }
-                                break;
                             }
-                            if (t == EMPTY) break;
-                            s = (s + 1) & (HSET - 1);
                         }
                     }
+                    tmask[q] = __ballot(tail);
+                    total += (u32)__popcll(tmask[q]);
                 }
-                const u64 mask = __ballot(tail);
-                if (mask) {
-                    const int first = __ffsll((long long)mask) - 1;
-                    if (H) {  // compact (no heavy values: the region is its own tail and stays where it is)
-                        u32 base = 0;
-                        if (lane == first) base = atomicAdd(&roff, (u32)__popcll(mask));
-                        base = __shfl(base, first);
-                        if (tail) w.B[lo + base + (u32)__popcll(mask & ((1ull << lane) - 1ull))] = k[q];
-                    }
-                    // top-byte histograms of the tail: bits 56..63 are one value almost always
-                    const u32 d56 = (u32)(k[q] >> 56), d56_0 = __shfl(d56, first);
-                    const u64 same = __ballot(tail && d56 == d56_0);
-                    if (lane == first) atomicAdd(&h56[d56_0], (u32)__popcll(same));
+            } else {
+#pragma unroll
+                for (int q = 0; q < ITEMS; ++q) {
+                    tmask[q] = __ballot(c0 + q * WG + tid < rn);
+                    total += (u32)__popcll(tmask[q]);
+                }
+            }
+            if (total) {  // (wave-uniform)
+                u32 base = 0;
+                if (H) {  // compact (no heavy values: the region is its own tail and stays where it is)
+                    if (lane == 0) base = atomicAdd(&roff, total);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                }
+                // top-byte histograms of the tail; bits 56..63 are one value almost always: one add per wave then
+                u32 d56_0 = 0;
+                u32 agree = 1;
+#pragma unroll
+                for (int q = 0; q < ITEMS; ++q) {
+                    const bool tail = (tmask[q] >> lane) & 1ull;
                     if (tail) {
-                        if (d56 != d56_0) atomicAdd(&h56[d56], 1u);
+                        if (H) w.B[lo + base + (u32)__popcll(tmask[q] & lt)] = k[q];
                         atomicAdd(&h48[cp + ((u32)(k[q] >> 48) & 255u)], 1u);
                         o |= k[q];
                         no |= ~k[q];
+                    }
+                    base += (u32)__popcll(tmask[q]);
+                }
+                {
+                    // first tail key of the wave: lane `fl` of round `fq`
+                    u64 kf = 0;
+                    bool got = false;
+#pragma unroll
+                    for (int q = 0; q < ITEMS; ++q) {
+                        if (!got && tmask[q]) {
+                            const int fl = __ffsll((long long)tmask[q]) - 1;
+                            kf = __shfl(k[q], fl);
+                            got = true;
+                        }
+                    }
+                    d56_0 = (u32)(kf >> 56);
+#pragma unroll
+                    for (int q = 0; q < ITEMS; ++q) {
+                        const bool tail = (tmask[q] >> lane) & 1ull;
+                        if (__ballot(tail && (u32)(k[q] >> 56) != d56_0)) agree = 0;
+                    }
+                    if (agree) {
+                        if (lane == 0) atomicAdd(&h56[d56_0], total);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < ITEMS; ++q)
+                            if ((tmask[q] >> lane) & 1ull) atomicAdd(&h56[(u32)(k[q] >> 56)], 1u);
                     }
                 }
             }
@@ -392,16 +400,9 @@ __global__ void __launch_bounds__(WG) k_strip(Ws w) {
     }
     o = wave_or(o);
     no = wave_or(no);
-#pragma unroll
-    for (int i = 0; i < HOT; ++i) hotc[i] = wave_sum(hotc[i]);
     if (lane == 0) {
         red[wid] = o;
         red[NWAVE + wid] = no;
-        if (H) {
-#pragma unroll
-            for (int i = 0; i < HOT; ++i)
-                if (hotc[i]) atomicAdd(&hc[w.hoti[i]], hotc[i]);  // (hotc > 0 only for i < nhot)
-        }
     }
     __syncthreads();
     if (tid == 0) {
@@ -416,7 +417,6 @@ __global__ void __launch_bounds__(WG) k_strip(Ws w) {
         }
         if (tail_total) atomicAdd(&w.ctl->n_tail, tail_total);
     }
-    if (w.exp & 2u) return;
     if (tid < 256) {
         u32 v = 0;
 #pragma unroll
@@ -424,29 +424,37 @@ __global__ void __launch_bounds__(WG) k_strip(Ws w) {
         if (v) atomicAdd(&w.root[0].cnt[tid], v);
         if (h56[tid]) atomicAdd(&w.root[1].cnt[tid], h56[tid]);
     }
+    // per-slot counts -> per-value counts in LDS, then ONE coalesced add per value: adds scattered over the array
+    // (slot order) are one memory-side request each and queue on its few lines (measured: 120 us for 266 values
+    // x 611 workgroups)
+    __syncthreads();
+    u32 *hc = h48;  // (256 * COPIES = H_MAX words, free again)
+    static_assert(256 * COPIES >= H_MAX, "h48 is reused for the per-value counts");
+    for (u32 i = tid; i < (u32)HSET; i += WG)
+        if (hk[i] != EMPTY) hc[hi[i]] = hs[i];
+    __syncthreads();
     for (u32 i = tid; i < H; i += WG)
         if (hc[i]) atomicAdd(&w.hcnt[i], hc[i]);
 }
 
 // ---- one MSD level --------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(WG) k_count(Ws w, int level) {
-    __shared__ u32 lc[256 * COPIES];
-    __shared__ u64 lor[256 * COPIES], lnor[256 * COPIES];
-    const int tid = threadIdx.x, lane = tid & 63;
+    __shared__ u32 lc[256];
+    __shared__ u64 lor[256], lnor[256];
+    const int tid = threadIdx.x;
     const int set = level & 1;
     if (w.ctl->err) return;  // a table overflowed in an earlier kernel: its entries are not to be trusted
     const u32 nt = w.ctl->ntile[level] < w.cap_tile ? w.ctl->ntile[level] : w.cap_tile;
     const u64 *src = (level & 1) ? w.C : w.B;
-    const u32 cp = (u32)(lane & (COPIES - 1)) * 256u;
     for (u32 t = blockIdx.x; t < nt; t += gridDim.x) {
         const TileRef ref = w.tiles[set][t];
         const Seg sg = w.segs[set][ref.seg];
         const u32 k0 = ref.k * TILE;
         const u32 m = sg.size - k0 < (u32)TILE ? sg.size - k0 : (u32)TILE;
-        for (int i = tid; i < 256 * COPIES; i += WG) {
-            lc[i] = 0;
-            lor[i] = 0;
-            lnor[i] = 0;
+        if (tid < 256) {
+            lc[tid] = 0;
+            lor[tid] = 0;
+            lnor[tid] = 0;
         }
         __syncthreads();
         const u64 *p = src + sg.off + k0;
@@ -456,79 +464,60 @@ __global__ void __launch_bounds__(WG) k_count(Ws w, int level) {
             const u32 j = q * WG + tid;
             k[q] = j < m ? p[j] : 0ull;
         }
+        // (independent adds, all in flight together: a bin that many lanes share costs ~2 cycles per lane,
+        // a dependent round trip per key costs far more)
 #pragma unroll
         for (int q = 0; q < ITEMS; ++q) {
             const u32 j = q * WG + tid;
-            const bool valid = j < m;
-            const u32 slot = cp + ((u32)(k[q] >> sg.shift) & 255u);
-            // lanes holding the first pending lane's KEY are counted by that lane (one repeated value is what
-            // fills most large bins); the others count for themselves, spread over COPIES copies
-            u64 rem = __ballot(valid);
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                if (rem == 0) break;
-                const int leader = __ffsll((long long)rem) - 1;
-                const u64 key0 = __shfl(k[q], leader);
-                const u64 same = __ballot(valid && k[q] == key0) & rem;
-                if (lane == leader) {
-                    atomicAdd(&lc[slot], (u32)__popcll(same));
-                    atomicOr(&lor[slot], key0);
-                    atomicOr(&lnor[slot], ~key0);
-                }
-                rem &= ~same;
-            }
-            if ((rem >> lane) & 1ull) {
-                atomicAdd(&lc[slot], 1u);
-                atomicOr(&lor[slot], k[q]);
-                atomicOr(&lnor[slot], ~k[q]);
+            if (j < m) {
+                const u32 d = (u32)(k[q] >> sg.shift) & 255u;
+                atomicAdd(&lc[d], 1u);
+                atomicOr(&lor[d], k[q]);
+                atomicOr(&lnor[d], ~k[q]);
             }
         }
         __syncthreads();
-        if (tid < 256) {
-            u32 c = 0;
-            u64 a = 0, b = 0;
-#pragma unroll
-            for (int i = 0; i < COPIES; ++i) {
-                c += lc[i * 256 + tid];
-                a |= lor[i * 256 + tid];
-                b |= lnor[i * 256 + tid];
-            }
-            if (c && !(w.exp & 4u)) {
-                HistRow *row = &w.rows[set][ref.seg];
-                atomicAdd(&row->cnt[tid], c);
-                atomicOr(&row->orv[tid], a);
-                atomicOr(&row->norv[tid], b);
-            }
+        if (tid < 256 && lc[tid]) {
+            HistRow *row = &w.rows[set][ref.seg];
+            atomicAdd(&row->cnt[tid], lc[tid]);
+            atomicOr(&row->orv[tid], lor[tid]);
+            atomicOr(&row->norv[tid], lnor[tid]);
         }
         __syncthreads();
     }
 }
 
 struct PlanLds {
-    u32 cls[256], ccnt[256], cshift[256], aux[256];
-    u32 pk_off[256], pk_size[256];
-    u32 bigid[256];
-    u32 npk, nchunk, nbig, ntl;
+    u32 cls[256], ccnt[256], cshift[256];
+    u32 prev_ne[256];   // (inclusive max-scan) 1 + index of the last non-empty bin at or before b
+    u32 next_bd[257];   // (suffix min-scan) first boundary bin at or after b; [256] = 256
+    u32 flag[256];      // bin starts a packed finish tile
+    u32 wtot[NWAVE];
     u32 ft_base, seg_base, tile_base, ok;
 };
 
 // Decide what becomes of every bin of one segment (run by ONE workgroup per segment; `coff` = the bins'
-// offsets inside the segment): finish tiles, or segments and tiles of the next level.
-__device__ void plan_segment(const Ws &w, int level, u32 seg_off, u32 shift, const HistRow *row, const u32 *coff,
-                             u32 dst_id, PlanLds &pl) {
+// offsets inside the segment, `seg_size` its keys): finish tiles, or segments and tiles of the next level.
+// Bins of <= CAP / 2 keys are packed: neighbours whose offsets fall into the same window of CAP / 2 share a tile
+// (it ends before two windows are over, so it holds < CAP keys); a bin of up to CAP keys is a tile of its own; a
+// larger bin whose keys are all equal is cut into tiles as it lies; any other larger bin is a segment of the next
+// level.  All of it in parallel over the 256 bins: a serial walk by one lane was the longest thing in the kernel.
+__device__ void plan_segment(const Ws &w, int level, u32 seg_off, u32 seg_size, u32 shift, const HistRow *row,
+                             const u32 *coff, u32 dst_id, PlanLds &pl) {
     const int tid = threadIdx.x;
     const int next = (level + 1) & 1;
+    u32 cls = 0, c = 0, csh = 0;  // 0 empty, 1 packed, 2 own tile, 3 large and all equal, 4 large
     if (tid < 256) {
-        const u32 c = row->cnt[tid];
+        c = row->cnt[tid];
         const u64 o = row->orv[tid], no = row->norv[tid];
         const bool known = (o | no) != 0;
         const u64 diff = o ^ ~no;
-        u32 cls = 0, csh = 0;  // 0 empty, 1 small, 2 large and all equal, 3 large
         if (c) {
-            if ((known && diff == 0) || shift == 0) cls = c <= (u32)CAP ? 1u : 2u;
-            else if (c <= (u32)CAP) cls = 1u;
+            if (c <= (u32)CAP / 2) cls = 1u;
+            else if (c <= (u32)CAP) cls = 2u;
+            else if ((known && diff == 0) || shift == 0) cls = 3u;
             else {
-                cls = 3u;
+                cls = 4u;
                 if (known) {
                     const int hb = 63 - __builtin_clzll(diff);
                     csh = hb > 7 ? (u32)(hb - 7) : 0u;
@@ -540,125 +529,127 @@ __device__ void plan_segment(const Ws &w, int level, u32 seg_off, u32 shift, con
         pl.cls[tid] = cls;
         pl.ccnt[tid] = c;
         pl.cshift[tid] = csh;
+        pl.prev_ne[tid] = c ? (u32)tid + 1u : 0u;
+    }
+    if (tid == 0) pl.next_bd[256] = 256u;
+    __syncthreads();
+    // inclusive max-scan of prev_ne (Hillis-Steele over 256 entries)
+    for (int o = 1; o < 256; o <<= 1) {
+        u32 v = 0;
+        if (tid < 256 && tid >= o) v = pl.prev_ne[tid - o];
+        __syncthreads();
+        if (tid < 256 && v > pl.prev_ne[tid]) pl.prev_ne[tid] = v;
+        __syncthreads();
+    }
+    // a packed bin starts a tile when the non-empty bin before it is none, is not packed, or lies in another window
+    if (tid < 256) {
+        u32 f = 0;
+        if (cls == 1u) {
+            const u32 p = tid ? pl.prev_ne[tid - 1] : 0u;  // 1 + index of the previous non-empty bin
+            f = 1u;
+            if (p && pl.cls[p - 1] == 1u && coff[p - 1] / (CAP / 2) == coff[tid] / (CAP / 2)) f = 0u;
+        }
+        pl.flag[tid] = f;
+        pl.next_bd[tid] = (f || cls >= 2u) ? (u32)tid : 256u;
     }
     __syncthreads();
+    // suffix min-scan of next_bd
+    for (int o = 1; o < 256; o <<= 1) {
+        u32 v = 256u;
+        if (tid < 256 && tid + o < 256) v = pl.next_bd[tid + o];
+        __syncthreads();
+        if (tid < 256 && v < pl.next_bd[tid]) pl.next_bd[tid] = v;
+        __syncthreads();
+    }
+    // how many of each, and where they go
+    const u32 is_ft = (tid < 256 && (pl.flag[tid] || cls == 2u)) ? 1u : 0u;
+    const u32 n_chunk = cls == 3u ? (c + CAP - 1) / CAP : 0u;
+    const u32 is_big = cls == 4u ? 1u : 0u;
+    const u32 n_tl = cls == 4u ? (c + TILE - 1) / TILE : 0u;
+    u32 tot_ft, tot_chunk, tot_big, tot_tl;
+    const u32 ex_ft = wg_excl_scan(is_ft, pl.wtot, tot_ft);
+    const u32 ex_chunk = wg_excl_scan(n_chunk, pl.wtot, tot_chunk);
+    const u32 ex_big = wg_excl_scan(is_big, pl.wtot, tot_big);
+    const u32 ex_tl = wg_excl_scan(n_tl, pl.wtot, tot_tl);
     if (tid == 0) {
-        u32 npk = 0, nchunk = 0, nbig = 0, ntl = 0, run_off = 0, run_size = 0;
-        for (int b = 0; b < 256; ++b) {
-            const u32 cls = pl.cls[b], c = pl.ccnt[b];
-            if (cls == 1u) {
-                if (run_size && run_size + c > (u32)CAP) {
-                    pl.pk_off[npk] = run_off;
-                    pl.pk_size[npk++] = run_size;
-                    run_size = 0;
-                }
-                if (!run_size) run_off = coff[b];
-                run_size += c;
-            } else if (cls >= 2u) {
-                if (run_size) {
-                    pl.pk_off[npk] = run_off;
-                    pl.pk_size[npk++] = run_size;
-                    run_size = 0;
-                }
-                if (cls == 2u) {
-                    pl.aux[b] = nchunk;  // first chunk tile of the bin
-                    nchunk += (c + CAP - 1) / CAP;
-                } else {
-                    pl.aux[b] = ntl;     // first tile of the new segment
-                    pl.bigid[nbig++] = b;
-                    ntl += (c + TILE - 1) / TILE;
-                }
-            }
-        }
-        if (run_size) {
-            pl.pk_off[npk] = run_off;
-            pl.pk_size[npk++] = run_size;
-        }
-        pl.npk = npk;
-        pl.nchunk = nchunk;
-        pl.nbig = nbig;
-        pl.ntl = ntl;
         u32 ok = 1;
-        pl.ft_base = atomicAdd(&w.ctl->nft, npk + nchunk);
-        if ((u64)pl.ft_base + npk + nchunk > (u64)w.cap_ft) {
+        pl.ft_base = atomicAdd(&w.ctl->nft, tot_ft + tot_chunk);
+        if ((u64)pl.ft_base + tot_ft + tot_chunk > (u64)w.cap_ft) {
             atomicOr(&w.ctl->err, ERR_FT);
             ok = 0;
         }
         pl.seg_base = pl.tile_base = 0;
-        if (nbig) {
+        if (tot_big) {
             if (level + 1 >= MAX_LEVELS) {  // cannot happen: the digit moves down by >= 8 bits per level
                 atomicOr(&w.ctl->err, ERR_LEVEL);
                 ok = 0;
             } else {
-                pl.seg_base = atomicAdd(&w.ctl->nseg[level + 1], nbig);
-                pl.tile_base = atomicAdd(&w.ctl->ntile[level + 1], ntl);
-                if ((u64)pl.seg_base + nbig > (u64)w.cap_seg) {
+                pl.seg_base = atomicAdd(&w.ctl->nseg[level + 1], tot_big);
+                pl.tile_base = atomicAdd(&w.ctl->ntile[level + 1], tot_tl);
+                if ((u64)pl.seg_base + tot_big > (u64)w.cap_seg) {
                     atomicOr(&w.ctl->err, ERR_SEG);
                     ok = 0;
                 }
-                if ((u64)pl.tile_base + ntl > (u64)w.cap_tile) {
+                if ((u64)pl.tile_base + tot_tl > (u64)w.cap_tile) {
                     atomicOr(&w.ctl->err, ERR_TILE);
                     ok = 0;
                 }
                 atomicMax(&w.ctl->levels_used, (u32)(level + 2));
-                atomicAdd(&w.ctl->segs_total, nbig);
+                atomicAdd(&w.ctl->segs_total, tot_big);
             }
         }
         pl.ok = ok;
     }
     __syncthreads();
     if (!pl.ok) return;  // (the error word is set: the result will be poisoned; write nothing out of range)
-    for (u32 i = tid; i < pl.npk; i += WG) {
+    if (is_ft) {
+        // the tile runs from this bin to the next boundary bin; everything between is packed bins back to back
+        const u32 nb = cls == 2u ? 256u : pl.next_bd[tid + 1];
         FTile f;
-        f.off = seg_off + pl.pk_off[i];
-        f.size = pl.pk_size[i];
+        f.off = seg_off + coff[tid];
+        f.size = cls == 2u ? c : (nb < 256u ? coff[nb] : seg_size) - coff[tid];
         f.src = dst_id;
         f.pad = 0;
-        w.ft[pl.ft_base + i] = f;
+        w.ft[pl.ft_base + ex_ft] = f;
     }
-    if (tid < 256 && pl.cls[tid] == 2u) {
-        const u32 c = pl.ccnt[tid];
-        const u32 nch = (c + CAP - 1) / CAP;
-        for (u32 q = 0; q < nch; ++q) {
-            FTile f;
-            f.off = seg_off + coff[tid] + q * CAP;
-            f.size = c - q * CAP < (u32)CAP ? c - q * CAP : (u32)CAP;
-            f.src = dst_id;
-            f.pad = 0;
-            w.ft[pl.ft_base + pl.npk + pl.aux[tid] + q] = f;
-        }
+    for (u32 q = 0; q < n_chunk; ++q) {
+        FTile f;
+        f.off = seg_off + coff[tid] + q * CAP;
+        f.size = c - q * CAP < (u32)CAP ? c - q * CAP : (u32)CAP;
+        f.src = dst_id;
+        f.pad = 0;
+        w.ft[pl.ft_base + tot_ft + ex_chunk + q] = f;
     }
-    for (u32 i = tid; i < pl.nbig; i += WG) {
-        const u32 b = pl.bigid[i];
+    if (is_big) {
         Seg s;
-        s.off = seg_off + coff[b];
-        s.size = pl.ccnt[b];
-        s.shift = pl.cshift[b];
+        s.off = seg_off + coff[tid];
+        s.size = c;
+        s.shift = csh;
         s.pad = 0;
-        w.segs[next][pl.seg_base + i] = s;
-        const u32 nt = (s.size + TILE - 1) / TILE;
-        TileRef *tr = w.tiles[next] + pl.tile_base + pl.aux[b];
-        for (u32 k = 0; k < nt; ++k) {
+        w.segs[next][pl.seg_base + ex_big] = s;
+        TileRef *tr = w.tiles[next] + pl.tile_base + ex_tl;
+        for (u32 k = 0; k < n_tl; ++k) {
             TileRef r;
-            r.seg = pl.seg_base + i;
+            r.seg = pl.seg_base + ex_big;
             r.k = k;
             tr[k] = r;
         }
     }
-    // clean histogram rows for the new segments
-    for (u32 i = 0; i < pl.nbig; ++i) {
-        u32 *p = (u32 *)&w.rows[next][pl.seg_base + i];
-        for (u32 j = tid; j < sizeof(HistRow) / 4; j += WG) p[j] = 0;
+    // clean histogram rows for the new segments (they are consecutive)
+    {
+        u32 *p = (u32 *)&w.rows[next][pl.seg_base];
+        const u32 words = tot_big * (u32)(sizeof(HistRow) / 4);
+        for (u32 j = tid; j < words; j += WG) p[j] = 0;
     }
 }
 
 template <bool ROOT>
 __global__ void __launch_bounds__(WG) k_scatter(Ws w, int level) {
     __shared__ u64 stage[TILE];
-    __shared__ u32 lcnt[256 * COPIES], lstart[256 * COPIES], gbase[256], coff[256], csize[256];
+    __shared__ u32 lcnt[256], lstart[256], gbase[256], coff[256], csize[256];
     __shared__ u32 wtot[NWAVE];
     __shared__ PlanLds pl;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
     const int set = level & 1;
     const u32 H = w.ctl->n_heavy;
     const u64 *src = ROOT ? (H ? (const u64 *)w.B : w.in) : ((level & 1) ? (const u64 *)w.C : (const u64 *)w.B);
@@ -699,7 +690,7 @@ __global__ void __launch_bounds__(WG) k_scatter(Ws w, int level) {
         }
         __syncthreads();
         if (blockIdx.x == 0) {
-            plan_segment(w, 0, 0u, sg.shift, row, coff, dst_id, pl);
+            plan_segment(w, 0, 0u, sg.size, sg.shift, row, coff, dst_id, pl);
             if (tid == 0) atomicMax(&w.ctl->levels_used, 1u);
         }
     } else {
@@ -729,57 +720,50 @@ __global__ void __launch_bounds__(WG) k_scatter(Ws w, int level) {
                 }
                 __syncthreads();
             }
-            if (ref.k == 0) plan_segment(w, level, sg.off, sg.shift, row, coff, dst_id, pl);
+            if (ref.k == 0) plan_segment(w, level, sg.off, sg.size, sg.shift, row, coff, dst_id, pl);
             base_in = sg.off;
             tile_lo = ref.k * TILE;
             tile_hi = sg.size - tile_lo < (u32)TILE ? sg.size : tile_lo + TILE;
         }
         for (u32 k0 = tile_lo; k0 < tile_hi; k0 += TILE) {
             const u32 m = tile_hi - k0 < (u32)TILE ? tile_hi - k0 : (u32)TILE;
-            for (int i = tid; i < 256 * COPIES; i += WG) lcnt[i] = 0;
+            if (tid < 256) lcnt[tid] = 0;
             __syncthreads();
             u64 k[ITEMS];
-            u32 rk[ITEMS], sl[ITEMS];
+            u32 rk[ITEMS];
             const u64 *p = src + base_in + k0;
 #pragma unroll
             for (int q = 0; q < ITEMS; ++q) {
                 const u32 j = q * WG + tid;
                 k[q] = j < m ? p[j] : 0ull;
             }
+            // the keys' ranks inside their bins: independent returning adds, all in flight together
 #pragma unroll
             for (int q = 0; q < ITEMS; ++q) {
                 const u32 j = q * WG + tid;
-                sl[q] = (((u32)(k[q] >> sg.shift) & 255u) << 2) + (u32)(lane & (COPIES - 1));  // bin-major
-                rk[q] = lds_rank_add(lcnt, sl[q], k[q], j < m, lane);
+                rk[q] = j < m ? atomicAdd(&lcnt[(u32)(k[q] >> sg.shift) & 255u], 1u) : 0u;
             }
             __syncthreads();
-            {
-                // exclusive scan over the 256 x COPIES slots (bin-major): where each slot starts in `stage`
-                static_assert(256 * COPIES == 2 * WG && COPIES == 4, "two slots per thread, four per bin");
-                const u32 c0 = lcnt[2 * tid], c1 = lcnt[2 * tid + 1];
-                u32 tot;
-                const u32 ex = wg_excl_scan(c0 + c1, wtot, tot);
-                lstart[2 * tid] = ex;
-                lstart[2 * tid + 1] = ex + c0;
-            }
-            __syncthreads();
+            u32 tot;
+            const u32 v = tid < 256 ? lcnt[tid] : 0u;
+            const u32 ex = wg_excl_scan(v, wtot, tot);
             if (tid < 256) {
-                const u32 v = lcnt[4 * tid] + lcnt[4 * tid + 1] + lcnt[4 * tid + 2] + lcnt[4 * tid + 3];
-                gbase[tid] = (v && !(w.exp & 1u)) ? atomicAdd(&row->cur[tid], v) : 0u;  // the bin's next free place: order is free
+                lstart[tid] = ex;
+                gbase[tid] = v ? atomicAdd(&row->cur[tid], v) : 0u;  // the bin's next free place: order is free
             }
+            __syncthreads();
 #pragma unroll
             for (int q = 0; q < ITEMS; ++q) {
                 const u32 j = q * WG + tid;
-                if (j < m) stage[lstart[sl[q]] + rk[q]] = k[q];
+                if (j < m) stage[lstart[(u32)(k[q] >> sg.shift) & 255u] + rk[q]] = k[q];
             }
             __syncthreads();
             for (u32 j = tid; j < m; j += WG) {
                 const u64 key = stage[j];
                 const u32 d = (u32)(key >> sg.shift) & 255u;
-                const u32 in_bin = gbase[d] + (j - lstart[4 * d]);
+                const u32 in_bin = gbase[d] + (j - lstart[d]);
                 // (counts that do not match the keys -- a caller overwriting them mid-sort -- must end as a
                 // poisoned result, never as a store outside the bin)
-                if (w.exp & 16u) continue;
                 if (in_bin < csize[d]) dst[(u64)sg.off + coff[d] + in_bin] = key;
                 else atomicOr(&w.ctl->err, ERR_RANGE);
             }
@@ -890,8 +874,7 @@ __global__ void __launch_bounds__(WG) k_finish(Ws w) {
 #pragma unroll
         for (int q = 0; q < ITEMS; ++q) {
             const u32 j = q * WG + tid;
-            u32 slot = (u32)((k[q] - mn) >> sh);
-            rk[q] = lds_rank_add(start, slot, k[q], j < m, lane);
+            rk[q] = j < m ? atomicAdd(&start[(u32)((k[q] - mn) >> sh)], 1u) : 0u;
         }
         __syncthreads();
         {
@@ -993,35 +976,61 @@ __global__ void __launch_bounds__(256) k_fill(Ws w) {
     __shared__ u64 hv[H_MAX];
     __shared__ u32 hp[H_MAX + 1];    // copies of heavy values below index i
     __shared__ u32 st[H_MAX];        // final index of the first copy of heavy value i
-    __shared__ u32 tmp[H_MAX + 1];
     const int tid = threadIdx.x;
     const u32 H = w.ctl->n_heavy;
     if (H == 0 || w.ctl->err) return;
-    // (<= 1024 values: a serial prefix by one thread per array is a few microseconds, once per workgroup)
-    for (u32 i = tid; i < H; i += 256) {
-        hv[i] = w.heavy[i];
-        tmp[i] = w.hcnt[i];
-    }
-    __syncthreads();
-    if (tid == 0) {
-        u32 run = 0;
-        for (u32 i = 0; i < H; ++i) {
-            hp[i] = run;
-            run += tmp[i];
+    // prefix sums over the heavy values (parallel: a serial walk of LDS by one lane costs ~100 cycles a step)
+    __shared__ u32 wtot[4];
+    auto scan4 = [&](u32 a0, u32 a1, u32 a2, u32 a3, u32 &total) {  // this thread's four consecutive entries
+        const int lane = tid & 63, wid = tid >> 6;
+        const u32 s = a0 + a1 + a2 + a3;
+        u32 inc = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
         }
-        hp[H] = run;
-    }
-    __syncthreads();
-    const u32 total = hp[H];
-    if ((u64)blockIdx.x * CHUNK >= total) return;
-    for (u32 i = tid; i <= H; i += 256) tmp[i] = w.gap[i];
-    __syncthreads();
-    if (tid == 0) {
-        u32 below = 0;
-        for (u32 i = 0; i < H; ++i) {
-            below += tmp[i];  // tail keys with at most i heavy values below them ARE below heavy value i
-            st[i] = hp[i] + below;
+        __syncthreads();
+        if (lane == 63) wtot[wid] = inc;
+        __syncthreads();
+        u32 off = 0, tot = 0;
+        for (int i = 0; i < 4; ++i) {
+            if (i < wid) off += wtot[i];
+            tot += wtot[i];
         }
+        total = tot;
+        return off + inc - s;
+    };
+    static_assert(H_MAX == 4 * 256, "four heavy values per thread");
+    u32 c[4], total;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const u32 i = tid * 4 + q;
+        c[q] = i < H ? w.hcnt[i] : 0u;
+        if (i < H) hv[i] = w.heavy[i];
+    }
+    u32 ex = scan4(c[0], c[1], c[2], c[3], total);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const u32 i = tid * 4 + q;
+        if (i <= H) hp[i] = ex;
+        ex += c[q];
+    }
+    if (tid == 0) hp[H] = total;
+    if ((u64)blockIdx.x * CHUNK >= total) return;  // (uniform)
+    u32 g[4], gtot;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const u32 i = tid * 4 + q;
+        g[q] = i < H ? w.gap[i] : 0u;
+    }
+    u32 gex = scan4(g[0], g[1], g[2], g[3], gtot);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const u32 i = tid * 4 + q;
+        gex += g[q];  // tail keys with at most i heavy values below them ARE below heavy value i
+        if (i < H) st[i] = hp[i] + gex;
     }
     __syncthreads();
     auto run_of = [&](u64 x) {  // last i with hp[i] <= x
@@ -1060,7 +1069,7 @@ __global__ void k_force_error(Ctl *ctl) { atomicOr(&ctl->err, ERR_DEBUG); }
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Layout {
-    size_t B, C, ctl, heavy, hcnt, gap, hotv, hoti, root, rcnt, segs[2], rows[2], tiles[2], ft, end;
+    size_t B, C, ctl, heavy, hcnt, gap, root, rcnt, segs[2], rows[2], tiles[2], ft, end;
     u32 regions, cap_seg, cap_tile, cap_ft;
     size_t clear_from, clear_bytes;
 };
@@ -1079,8 +1088,6 @@ Layout layout_for(u64 n) {
     L.heavy = p; p += align256(H_MAX * sizeof(u64));
     L.hcnt = p; p += align256(H_MAX * sizeof(u32));
     L.gap = p; p += align256((H_MAX + 1) * sizeof(u32));
-    L.hotv = p; p += align256(HOT * sizeof(u64));
-    L.hoti = p; p += align256(HOT * sizeof(u32));
     L.root = p; p += align256(2 * sizeof(HistRow));
     L.clear_bytes = p - L.clear_from;
     L.rcnt = p; p += align256((size_t)L.regions * sizeof(u32));
@@ -1111,8 +1118,6 @@ int mc_sort_keys(const uint64_t *in, uint64_t n, uint64_t *out, void *workspace,
     w.heavy = (u64 *)(base + L.heavy);
     w.hcnt = (u32 *)(base + L.hcnt);
     w.gap = (u32 *)(base + L.gap);
-    w.hotv = (u64 *)(base + L.hotv);
-    w.hoti = (u32 *)(base + L.hoti);
     w.root = (HistRow *)(base + L.root);
     w.rcnt = (u32 *)(base + L.rcnt);
     for (int i = 0; i < 2; ++i) {
@@ -1130,7 +1135,6 @@ int mc_sort_keys(const uint64_t *in, uint64_t n, uint64_t *out, void *workspace,
     w.cap_seg = L.cap_seg;
     w.cap_tile = L.cap_tile;
     w.cap_ft = L.cap_ft;
-    w.exp = getenv("MC_SORT_EXP") ? (u32)atoi(getenv("MC_SORT_EXP")) : 0u;
     if (debug_fail) w.cap_ft = 1;  // the first plan overflows the finish-tile table: the failure path, on demand
     if (err_word_out) *err_word_out = &w.ctl->err;
 

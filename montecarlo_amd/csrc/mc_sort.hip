@@ -53,13 +53,13 @@ constexpr int TILE = 4096;         // keys per count / scatter tile
 constexpr int WG = 512;            // threads of the strip / count / scatter / finish workgroups
 constexpr int ITEMS = TILE / WG;   // keys per lane and tile
 constexpr int NWAVE = WG / 64;
-constexpr int REGION = 8192;       // keys per strip region (its tail is stored at the region's own offset)
-constexpr int SNIFF_S = 8192, SNIFF_SLOTS = 12288, SNIFF_MIN = 4, SNIFF_THREADS = 1024;
+constexpr int REGION = 12288;      // keys per strip region (its tail is stored at the region's own offset)
+constexpr int SNIFF_S = 16384, SNIFF_SLOTS = 16384, SNIFF_MIN = 5, SNIFF_THREADS = 1024, SNIFF_PROBES = 8;
 constexpr int H_MAX = 1024, HSET = 2048;
 constexpr int COPIES = 4;          // lane-sliced copies of LDS histograms: lanes l, l+4, ... share one
 constexpr int MAX_LEVELS = 8;      // 64 bits / 8
 constexpr int BINS = 4096;         // buckets of a finish tile
-constexpr int SMALL_GROUP = 32;    // bucket sizes ranked by counting, lane per key
+constexpr int SMALL_GROUP = 16;    // bucket sizes ranked by counting, lane per key
 constexpr u64 EMPTY = ~0ull;
 
 enum { ERR_SEG = 1u, ERR_TILE = 2u, ERR_FT = 4u, ERR_RANGE = 8u, ERR_DEBUG = 16u, ERR_LEVEL = 32u };
@@ -163,35 +163,60 @@ __device__ __forceinline__ u32 wave_sum(u32 v) {
 }
 
 // ---- heavy values -------------------------------------------------------------------------------------
-// One workgroup: SNIFF_S keys at a fixed stride into an LDS hash table (value, occurrences); the values seen
-// SNIFF_MIN times or more (at most H_MAX: the bar is raised until they fit) are the heavy values, written in
-// ascending order.
+// One workgroup: SNIFF_S keys (blocks of 16 consecutive keys, evenly spaced) are counted in an LDS hash table of
+// 32-bit tags (a 64-bit table for that many samples would not fit); the slots seen SNIFF_MIN times or more (at
+// most H_MAX: the bar is raised until they fit) are the heavy candidates; a second look at the same keys lists
+// the key behind each such slot (the first one that claims it: two values sharing a tag cost one of them its
+// place, nothing else), and the list is written in ascending order.
+__device__ __forceinline__ u32 sniff_mix(u64 k) {
+    const u32 lo = (u32)k, hi = (u32)(k >> 32);
+    u32 x = lo ^ (hi * 0x9E3779B1u);
+    x ^= x >> 15;
+    return x * 0x85EBCA6Bu;
+}
+
 __global__ void __launch_bounds__(SNIFF_THREADS) k_sniff(Ws w) {
-    __shared__ u64 tk[SNIFF_SLOTS];
-    __shared__ u32 tc[SNIFF_SLOTS / 2];  // two 16-bit counts per word
+    constexpr int PER = SNIFF_S / SNIFF_THREADS;
+    static_assert(SNIFF_SLOTS == 16384, "slot = top 14 bits of the mix");
+    __shared__ u32 tag[SNIFF_SLOTS];          // 0 = empty
+    __shared__ u32 tc[SNIFF_SLOTS / 2];       // two 16-bit counts per word
+    __shared__ u32 claim[SNIFF_SLOTS / 32];
     __shared__ u64 list[H_MAX];
     __shared__ u32 nlist;
     const u32 n = w.n;
     const int tid = threadIdx.x;
-    if (n < (u32)SNIFF_S * 8) return;  // small inputs: no heavy values (n_heavy stays 0)
-    for (int i = tid; i < SNIFF_SLOTS; i += SNIFF_THREADS) tk[i] = EMPTY;
+    if (n < (u32)SNIFF_S * 4) return;  // small inputs: no heavy values (n_heavy stays 0)
+    for (int i = tid; i < SNIFF_SLOTS; i += SNIFF_THREADS) tag[i] = 0;
     for (int i = tid; i < SNIFF_SLOTS / 2; i += SNIFF_THREADS) tc[i] = 0;
+    for (int i = tid; i < SNIFF_SLOTS / 32; i += SNIFF_THREADS) claim[i] = 0;
     __syncthreads();
-    const u32 stride = n / SNIFF_S;
-    u64 k[SNIFF_S / SNIFF_THREADS];
+    // (blocks of consecutive keys: 1024 pages touched; every key at its own stride was one address translation
+    // per key for this one compute unit, most of the kernel's time)
+    constexpr int BLOCK = 16, BLOCKS = SNIFF_S / BLOCK;
+    const u64 bstride = n / BLOCKS;
+    u64 k[PER];
+    u32 slot[PER];
 #pragma unroll
-    for (int q = 0; q < SNIFF_S / SNIFF_THREADS; ++q) k[q] = w.in[(u64)(q * SNIFF_THREADS + tid) * stride + stride / 2];
+    for (int q = 0; q < PER; ++q) {
+        const u32 block = (u32)((q * SNIFF_THREADS + tid) / BLOCK);
+        k[q] = w.in[(u64)block * bstride + (u32)(tid % BLOCK)];
+    }
 #pragma unroll
-    for (int q = 0; q < SNIFF_S / SNIFF_THREADS; ++q) {
-        if (k[q] == EMPTY) continue;
-        u32 s = (u32)(((u64)hset_hash(k[q]) * SNIFF_SLOTS) >> 24);  // hset_hash has 24 bits
-        for (;;) {  // at most SNIFF_S of SNIFF_SLOTS slots are ever taken: the probe ends
-            const u64 old = atomicCAS(&tk[s], EMPTY, k[q]);
-            if (old == EMPTY || old == k[q]) {
+    for (int q = 0; q < PER; ++q) {
+        const u32 x = sniff_mix(k[q]);
+        const u32 t = x | 1u;
+        u32 s = x >> 18;
+        slot[q] = 0xFFFFFFFFu;
+        // a sample that finds no place within SNIFF_PROBES slots is dropped: with few repeated values the table
+        // fills up (as many samples as slots) and an unbounded probe would walk most of it for every sample
+        for (int probe = 0; probe < SNIFF_PROBES; ++probe) {
+            const u32 old = atomicCAS(&tag[s], 0u, t);
+            if (old == 0u || old == t) {
                 atomicAdd(&tc[s >> 1], 1u << (16 * (s & 1u)));
+                slot[q] = s;
                 break;
             }
-            s = s + 1 == (u32)SNIFF_SLOTS ? 0u : s + 1;
+            s = (s + 1) & (SNIFF_SLOTS - 1);
         }
     }
     u32 bar = SNIFF_MIN;
@@ -206,18 +231,22 @@ __global__ void __launch_bounds__(SNIFF_THREADS) k_sniff(Ws w) {
         if (nlist <= (u32)H_MAX) break;
         ++bar;
     }
-    const u32 H = nlist;
     __syncthreads();
     if (tid == 0) nlist = 0;
     __syncthreads();
-    for (int i = tid; i < SNIFF_SLOTS; i += SNIFF_THREADS) {
-        const u32 c = (tc[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
-        if (c >= bar) {
-            const u32 p = atomicAdd(&nlist, 1u);
-            list[p] = tk[i];  // p < H <= H_MAX
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const u32 s = slot[q];
+        if (s != 0xFFFFFFFFu && ((tc[s >> 1] >> (16 * (s & 1u))) & 0xFFFFu) >= bar) {
+            const u32 bit = 1u << (s & 31u);
+            if (!(atomicOr(&claim[s >> 5], bit) & bit)) {
+                const u32 p = atomicAdd(&nlist, 1u);
+                list[p] = k[q];  // one claim per slot, at most H_MAX slots at the bar
+            }
         }
     }
     __syncthreads();
+    const u32 H = nlist;
     for (u32 i = tid; i < H; i += SNIFF_THREADS) {  // the values are distinct: rank = position
         const u64 v = list[i];
         u32 r = 0;
@@ -237,6 +266,100 @@ __device__ __forceinline__ u32 strip_hash(u64 k) {
     u32 x = lo ^ (hi * 0x9E3779B1u);
     x ^= x >> 15;
     return (x * 0x85EBCA6Bu) >> 21;  // 11 bits = HSET slots
+}
+
+// One tile of k_strip.  FULL: every lane holds ITEMS keys (no validity tests at all: they were a branch per load
+// and per key).  Heavy test without branches: the key's home slot and the next one are read together; only a key
+// that meets two other values there walks on (rare: the table is at most half full, 14 % on the headline model).
+template <bool FULL>
+__device__ __forceinline__ void strip_tile(const u64 (&k)[ITEMS], u32 c0, u32 rn, u64 lo, u32 H, const u64 *hk,
+                                           u32 *hs, u32 *h48, u32 *h56, u32 *roff, u64 *B, u64 &o, u64 &no) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const u32 cp = (u32)(lane & (COPIES - 1)) * 256u;
+    const u64 lt = (1ull << lane) - 1ull;
+    u64 tmask[ITEMS];
+    u32 total = 0;
+    if (H) {
+        u32 s[ITEMS];
+        u64 a[ITEMS], b[ITEMS];
+#pragma unroll
+        for (int q = 0; q < ITEMS; ++q) {
+            s[q] = strip_hash(k[q]);
+            a[q] = hk[s[q]];
+            b[q] = hk[s[q] + 1];  // (slot HSET is a spare that stays empty)
+        }
+#pragma unroll
+        for (int q = 0; q < ITEMS; ++q) {
+            const bool valid = FULL || c0 + q * WG + tid < rn;
+            const bool real = valid && k[q] != EMPTY;  // (a key equal to the empty marker is never heavy)
+            const bool hit_a = real && a[q] == k[q];
+            const bool hit_b = real && !hit_a && a[q] != EMPTY && b[q] == k[q];
+            // (a miss is decided when a slot is empty; the table wraps, so the spare slot decides nothing)
+            bool walk = real && !hit_a && !hit_b && a[q] != EMPTY && (b[q] != EMPTY || s[q] + 1 == (u32)HSET);
+            bool heavy = hit_a || hit_b;
+            u32 slot = s[q] + (hit_b ? 1u : 0u);
+            if (__ballot(walk)) {  // (rare)
+                if (walk) {
+                    u32 t = s[q] + 1 == (u32)HSET ? 0u : ((s[q] + 2) & (HSET - 1));
+                    for (;;) {
+                        const u64 v = hk[t];
+                        if (v == k[q]) {
+                            heavy = true;
+                            slot = t;
+                            break;
+                        }
+                        if (v == EMPTY) break;
+                        t = (t + 1) & (HSET - 1);
+                    }
+                }
+            }
+            if (heavy) atomicAdd(&hs[slot], 1u);
+            tmask[q] = __ballot(valid && !heavy);
+            total += (u32)__popcll(tmask[q]);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < ITEMS; ++q) {
+            tmask[q] = __ballot(FULL || c0 + q * WG + tid < rn);
+            total += (u32)__popcll(tmask[q]);
+        }
+    }
+    if (total == 0) return;  // (wave-uniform)
+    u32 base = 0;
+    if (H) {  // compact (no heavy values: the region is its own tail and stays where it is)
+        if (lane == 0) base = atomicAdd(roff, total);
+        base = __builtin_amdgcn_readfirstlane(base);
+    }
+    // top-byte histograms of the tail
+    u64 kf = 0;  // the wave's first tail key
+    bool got = false;
+#pragma unroll
+    for (int q = 0; q < ITEMS; ++q) {
+        const bool tail = (tmask[q] >> lane) & 1ull;
+        if (tail) {
+            if (H) B[lo + base + (u32)__popcll(tmask[q] & lt)] = k[q];
+            atomicAdd(&h48[cp + ((u32)(k[q] >> 48) & 255u)], 1u);
+            o |= k[q];
+            no |= ~k[q];
+        }
+        base += (u32)__popcll(tmask[q]);
+        if (!got && tmask[q]) {
+            kf = __shfl(k[q], __ffsll((long long)tmask[q]) - 1);
+            got = true;
+        }
+    }
+    // bits 56..63 are one value almost always: one add per wave then
+    const u32 d56_0 = (u32)(kf >> 56);
+    u64 differ = 0;
+#pragma unroll
+    for (int q = 0; q < ITEMS; ++q) differ |= __ballot(((tmask[q] >> lane) & 1ull) && (u32)(k[q] >> 56) != d56_0);
+    if (!differ) {
+        if (lane == 0) atomicAdd(&h56[d56_0], total);
+    } else {
+#pragma unroll
+        for (int q = 0; q < ITEMS; ++q)
+            if ((tmask[q] >> lane) & 1ull) atomicAdd(&h56[(u32)(k[q] >> 56)], 1u);
+    }
 }
 
 __global__ void __launch_bounds__(WG) k_strip(Ws w) {
@@ -270,8 +393,6 @@ __global__ void __launch_bounds__(WG) k_strip(Ws w) {
     __syncthreads();
     u64 o = 0, no = 0;
     u32 tail_total = 0;  // (thread 0)
-    const u32 cp = (u32)(lane & (COPIES - 1)) * 256u;
-    const u64 lt = (1ull << lane) - 1ull;
     for (u32 r = blockIdx.x; r < w.regions; r += gridDim.x) {
         const u64 lo = (u64)r * REGION;
         const u32 rn = (u32)(n - lo < (u64)REGION ? n - lo : (u64)REGION);
@@ -281,7 +402,7 @@ __global__ void __launch_bounds__(WG) k_strip(Ws w) {
 #pragma unroll
         for (int q = 0; q < ITEMS; ++q) {
             const u32 j = q * WG + tid;
-            nk[q] = j < rn ? w.in[lo + j] : EMPTY;
+            nk[q] = w.in[lo + (j < rn ? j : rn - 1)];  // (clamped, not guarded: no branch; rn >= 1)
         }
         for (u32 c0 = 0; c0 < rn; c0 += TILE) {
 #pragma unroll
@@ -290,105 +411,11 @@ __global__ void __launch_bounds__(WG) k_strip(Ws w) {
 #pragma unroll
                 for (int q = 0; q < ITEMS; ++q) {
                     const u32 j = c0 + TILE + q * WG + tid;
-                    nk[q] = j < rn ? w.in[lo + j] : EMPTY;
+                    nk[q] = w.in[lo + (j < rn ? j : rn - 1)];
                 }
             }
-            u64 tmask[ITEMS];
-            u32 total = 0;
-            if (H) {
-                u32 s[ITEMS];
-                u64 a[ITEMS], b[ITEMS];
-#pragma unroll
-                for (int q = 0; q < ITEMS; ++q) {
-                    s[q] = strip_hash(k[q]);
-                    a[q] = hk[s[q]];
-                    b[q] = hk[s[q] + 1];
-                }
-#pragma unroll
-                for (int q = 0; q < ITEMS; ++q) {
-                    const bool valid = c0 + q * WG + tid < rn;
-                    bool tail = valid;
-                    if (valid && k[q] != EMPTY) {  // (a key equal to the empty marker is never heavy)
-                        if (a[q] == k[q]) {
-                            atomicAdd(&hs[s[q]], 1u);
-                            tail = false;
-                        } else if (a[q] != EMPTY) {
-                            if (b[q] == k[q] && s[q] + 1 < (u32)HSET) {
-                                atomicAdd(&hs[s[q] + 1], 1u);
-                                tail = false;
-                            } else if (b[q] != EMPTY || s[q] + 1 == (u32)HSET) {
-                                u32 t = (s[q] + 2) & (HSET - 1);  // (rare: a run of three or more taken slots)
-                                if (s[q] + 1 == (u32)HSET) t = 0;
-                                for (;;) {
-                                    const u64 v = hk[t];
-                                    if (v == k[q]) {
-                                        atomicAdd(&hs[t], 1u);
-                                        tail = false;
-                                        break;
-                                    }
-                                    if (v == EMPTY) break;
-                                    t = (t + 1) & (HSET - 1);
-                                }
-                            }
-                        }
-                    }
-                    tmask[q] = __ballot(tail);
-                    total += (u32)__popcll(tmask[q]);
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < ITEMS; ++q) {
-                    tmask[q] = __ballot(c0 + q * WG + tid < rn);
-                    total += (u32)__popcll(tmask[q]);
-                }
-            }
-            if (total) {  // (wave-uniform)
-                u32 base = 0;
-                if (H) {  // compact (no heavy values: the region is its own tail and stays where it is)
-                    if (lane == 0) base = atomicAdd(&roff, total);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                }
-                // top-byte histograms of the tail; bits 56..63 are one value almost always: one add per wave then
-                u32 d56_0 = 0;
-                u32 agree = 1;
-#pragma unroll
-                for (int q = 0; q < ITEMS; ++q) {
-                    const bool tail = (tmask[q] >> lane) & 1ull;
-                    if (tail) {
-                        if (H) w.B[lo + base + (u32)__popcll(tmask[q] & lt)] = k[q];
-                        atomicAdd(&h48[cp + ((u32)(k[q] >> 48) & 255u)], 1u);
-                        o |= k[q];
-                        no |= ~k[q];
-                    }
-                    base += (u32)__popcll(tmask[q]);
-                }
-                {
-                    // first tail key of the wave: lane `fl` of round `fq`
-                    u64 kf = 0;
-                    bool got = false;
-#pragma unroll
-                    for (int q = 0; q < ITEMS; ++q) {
-                        if (!got && tmask[q]) {
-                            const int fl = __ffsll((long long)tmask[q]) - 1;
-                            kf = __shfl(k[q], fl);
-                            got = true;
-                        }
-                    }
-                    d56_0 = (u32)(kf >> 56);
-#pragma unroll
-                    for (int q = 0; q < ITEMS; ++q) {
-                        const bool tail = (tmask[q] >> lane) & 1ull;
-                        if (__ballot(tail && (u32)(k[q] >> 56) != d56_0)) agree = 0;
-                    }
-                    if (agree) {
-                        if (lane == 0) atomicAdd(&h56[d56_0], total);
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < ITEMS; ++q)
-                            if ((tmask[q] >> lane) & 1ull) atomicAdd(&h56[(u32)(k[q] >> 56)], 1u);
-                    }
-                }
-            }
+            if (c0 + TILE <= rn) strip_tile<true>(k, c0, rn, lo, H, hk, hs, h48, h56, &roff, w.B, o, no);
+            else strip_tile<false>(k, c0, rn, lo, H, hk, hs, h48, h56, &roff, w.B, o, no);
         }
         __syncthreads();
         if (tid == 0) {
@@ -919,9 +946,15 @@ __global__ void __launch_bounds__(WG) k_finish(Ws w) {
             }
             if (g > 1) {
                 u32 r = 0;
-                for (u32 i = s; i < e; ++i) {
-                    const u64 o2 = stage[i];
-                    r += (o2 < key || (o2 == key && i < j)) ? 1u : 0u;
+                for (u32 i = s; i < e; i += 4) {  // (four independent reads a step: the bucket is <= 32 keys)
+                    const u64 o0 = stage[i];
+                    const u64 o1 = stage[i + 1 < e ? i + 1 : i];
+                    const u64 o2 = stage[i + 2 < e ? i + 2 : i];
+                    const u64 o3 = stage[i + 3 < e ? i + 3 : i];
+                    r += (o0 < key || (o0 == key && i < j)) ? 1u : 0u;
+                    r += (i + 1 < e && (o1 < key || (o1 == key && i + 1 < j))) ? 1u : 0u;
+                    r += (i + 2 < e && (o2 < key || (o2 == key && i + 2 < j))) ? 1u : 0u;
+                    r += (i + 3 < e && (o3 < key || (o3 == key && i + 3 < j))) ? 1u : 0u;
                 }
                 pos = s + r;
             }

@@ -3,10 +3,13 @@
 (threshold 10) trained on 100k synthetic Zipfian passwords; one "step" = the whole
 guess-number hot path on one GPU:
 
-    sample N=1e7 strings (k_sample) -> radix sort + prefix sum of 1/(n p) (mc_rank_build)
-    -> score T=1e6 test passwords (k_score) -> bisect them into the curve (k_query)
+    sample N=1e7 strings (k_sample) -> sort + prefix sum of 1/(n p) (mc_rank_build)
+    -> score T=1e6 test passwords (k_score) -> their stable order by -log2 p (mc_order_keys)
+    -> bisect them into the curve (k_query)
     [-> all-reduce of the per-test partial sums when world_size > 1, on its own stream beside the
         next step's sampling]
+    -> monotone guess numbers (mc_guess_numbers) -> ranks, order and sorted -log2 p to pinned host memory
+       (20 B per test password, on a copy stream beside the next step)
 
 Inputs (compiled tables, encoded test set) are resident in HBM before the timed region.
 Prints ONE JSON line on rank 0.  `python bench.py --gpus N --steps K --warmup W`; for N > 1
@@ -23,19 +26,13 @@ import time
 import numpy as np
 import torch
 
-if "--rehearse-on-one-gpu" not in sys.argv and "--overlap-score" not in sys.argv:
-    # this process has the GPU to itself and runs the sort alone on its stream: select the sort's
-    # exclusive-GPU tile assignment (csrc/mc_rank.hip; the library's default takes tiles by ticket, which is
-    # safe beside other kernels and slower); read once when the library loads, reported in `config`
-    os.environ.setdefault("MC_SORT_EXCLUSIVE", "1")
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("TQDM_DISABLE", "1")
 
 from montecarlo_amd import synth  # noqa: E402
 from montecarlo_amd.backwords_simulator import BackWordsMonteCarlo  # noqa: E402
-from montecarlo_amd.engine import DeviceRank  # noqa: E402
+from montecarlo_amd.engine import DeviceRank, device_guess_numbers, device_order  # noqa: E402
 from montecarlo_amd import _native as nv  # noqa: E402
 from montecarlo_amd import dist as mcd  # noqa: E402
 
@@ -54,9 +51,9 @@ except (OSError, ValueError):
 # from the compare counter: an upper bound, single-threshold buckets compare without a read),
 # 8 B key written per sample.  All counts come from the device counters of the timed launches.
 B_DRAW, B_INDIRECT, B_PROBE, B_SAMPLE = 16, 16, 8, 8
-# rank build: 8 B/key histogram read + 16 B/key per ACTIVE radix pass + 8 B/key
-# weight sums + 16 B/key positions
-B_HIST, B_PASS, B_SCAN = 8, 16, 24
+# rank build, algorithmic minimum: every key read once and written once in order (16 B),
+# weight sums read it again (8 B), positions read it and write the running sum (16 B)
+B_RANK = 40
 
 
 def main():
@@ -69,8 +66,7 @@ def main():
     ap.add_argument("--train-lines", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap-score", action="store_true",
-                    help="score the test set on a second stream beside the rank build (the sort then takes its "
-                         "tiles by ticket; slower than the default since the sort got faster on its own)")
+                    help="score the test set on a second stream beside the rank build")
     ap.add_argument("--serial", action="store_true", help=argparse.SUPPRESS)        # (the default now)
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="rehearsal of the multi-rank control flow on a 1-GPU box: every rank uses cuda:0 and the "
@@ -112,23 +108,36 @@ def main():
     positions = torch.empty_like(keys)
     ws = torch.empty(nv.lib.mc_rank_workspace_bytes(N), dtype=torch.uint8, device=dev)
     t_ml2p = torch.empty(T, dtype=torch.float64, device=dev)
-    # two result buffers and a stream of its own for the collective: a step's all-reduce runs beside the
-    # next step's SAMPLING (world > 1); the main stream waits for it before the next rank build, whose
-    # persistent sort wants the GPU to itself
+    # two sets of result buffers, a stream of its own for the collective and one for the copies to the host:
+    # a step's all-reduce (world > 1) runs beside the next step's SAMPLING and the main stream waits for it
+    # before the next rank build; the copies run beside whatever follows and the main stream waits for them only
+    # when it is about to write the same set again, two steps later
     q_pos = [torch.empty(T, dtype=torch.float64, device=dev) for _ in range(2)]
-    reduced = [None, None]
+    t_sorted = [torch.empty(T, dtype=torch.float64, device=dev) for _ in range(2)]
+    t_order = [torch.empty(T, dtype=torch.int32, device=dev) for _ in range(2)]
+    g_rank = [torch.empty(T, dtype=torch.int64, device=dev) for _ in range(2)]
+    g_exact = [torch.empty(1, dtype=torch.int64, device=dev) for _ in range(2)]
+    host = [{"rank": torch.empty(T, dtype=torch.int64).pin_memory(), "order": torch.empty(T, dtype=torch.int32).pin_memory(),
+             "ml2p": torch.empty(T, dtype=torch.float64).pin_memory(), "exact": torch.empty(1, dtype=torch.int64).pin_memory()}
+            for _ in range(2)]
+    ws_order = torch.empty(nv.lib.mc_order_workspace_bytes(T), dtype=torch.uint8, device=dev)
+    ws_gn = torch.empty(nv.lib.mc_guess_numbers_workspace_bytes(T), dtype=torch.uint8, device=dev)
+    reduced, copied = [None, None], [None, None]
     comm = torch.cuda.Stream(device=dev) if world > 1 else None
+    copy = torch.cuda.Stream(device=dev)
     q_cnt = torch.empty(T, dtype=torch.int64, device=dev)
     seed = 20250304
 
-    ev = {k: [] for k in ("sample", "rank", "score", "query")}
+    ev = {k: [] for k in ("sample", "rank", "score", "order", "query", "guess_numbers", "d2h")}
     side = torch.cuda.Stream(device=dev) if args.overlap_score else None
     main_stream = torch.cuda.current_stream(dev)
+
+    rk_last = [None]
 
     def step(it: int, timed: bool):
         """sample -> rank build -> score -> queries on the main stream (--overlap-score: the test set is
         scored on a second stream beside the rank build; it does not depend on the samples)."""
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(12)]
         slot = it & 1
         first = (it * world + rank) * N                     # disjoint Philox sample ids per rank and step
         marks[0].record()
@@ -147,6 +156,7 @@ def main():
                 dm.score_device(d_syms, d_off, T, out=t_ml2p)
                 marks[4].record()
         rk = DeviceRank(keys, n_global=N * world, workspace=ws, keys_sorted=keys_sorted, positions=positions)
+        rk_last[0] = rk
         marks[2].record()
         if side is None:
             marks[3].record()
@@ -154,10 +164,21 @@ def main():
             marks[4].record()
         else:
             main_stream.wait_event(marks[4])
+        if copied[slot] is not None:                        # this set's copies of two steps ago
+            main_stream.wait_event(copied[slot])
+            copied[slot] = None
         marks[5].record()
-        rk.query(t_ml2p, out_pos=q_pos[slot], out_cnt=q_cnt)
-        if comm is not None:
-            # ONE RCCL all-reduce (8 MB) per step, on the collective's stream behind the queries
+        device_order(t_ml2p, out_sorted=t_sorted[slot], out_order=t_order[slot], workspace=ws_order)
+        marks[6].record()
+        rk.query(t_sorted[slot], out_pos=q_pos[slot], out_cnt=q_cnt)
+        marks[7].record()
+        if comm is None:
+            device_guess_numbers(q_pos[slot], q_cnt, True, out=g_rank[slot], workspace=ws_gn, exact=g_exact[slot])
+            marks[8].record()
+            ready = marks[8]
+        else:
+            # ONE RCCL all-reduce (8 MB) per step, on the collective's stream behind the queries, then the guess
+            # numbers from the summed positions (a summed position is > 0 exactly when some shard counted a sample)
             asked = torch.cuda.Event()
             asked.record(main_stream)
             comm.wait_event(asked)
@@ -168,14 +189,28 @@ def main():
                 torch.cuda.synchronize()
             with torch.cuda.stream(comm):
                 mcd.combine_positions(q_pos[slot])
-                reduced[slot] = torch.cuda.Event()
-                reduced[slot].record(comm)
-        marks[6].record()
+                marks[9].record()
+                device_guess_numbers(q_pos[slot], None, True, out=g_rank[slot], workspace=ws_gn, exact=g_exact[slot])
+                marks[8].record()
+                reduced[slot] = marks[8]
+            ready = marks[8]
+        copy.wait_event(ready)
+        with torch.cuda.stream(copy):
+            marks[10].record()
+            host[slot]["rank"].copy_(g_rank[slot], non_blocking=True)
+            host[slot]["order"].copy_(t_order[slot], non_blocking=True)
+            host[slot]["ml2p"].copy_(t_sorted[slot], non_blocking=True)
+            host[slot]["exact"].copy_(g_exact[slot], non_blocking=True)
+            marks[11].record()
+            copied[slot] = marks[11]
         if timed:
             ev["sample"].append((marks[0], marks[1]))
             ev["rank"].append((marks[1], marks[2]))
             ev["score"].append((marks[3], marks[4]))
-            ev["query"].append((marks[5], marks[6]))
+            ev["order"].append((marks[5], marks[6]))
+            ev["query"].append((marks[6], marks[7]))
+            ev["guess_numbers"].append((marks[7] if comm is None else marks[9], marks[8]))
+            ev["d2h"].append((marks[10], marks[11]))
 
     def fence():
         torch.cuda.synchronize()                            # (every stream of the device: the collective's too)
@@ -204,16 +239,29 @@ def main():
     assert bool(torch.isfinite(keys).all()) and bool((keys_sorted[1:] >= keys_sorted[:-1]).all())
     assert bool(torch.isfinite(positions).all()) and bool((positions[1:] >= positions[:-1]).all())
 
-    # radix passes that do anything on the last step's keys (mc_rank_build skips constant digits)
-    kb = keys.view(torch.uint8).view(N, 8)
-    active = int(sum(int(kb[:, b].min()) != int(kb[:, b].max()) for b in range(8)))
+    # the last two steps' results as the host received them: guess numbers strictly increasing as far as they
+    # fit int64 (beyond, the array carries the estimates for the caller's big integers: passwords the model
+    # cannot spell sit at the sum of all weights), the order a permutation under which the scores ascend
+    for h in host[:min(2, args.steps + args.warmup)]:
+        exact = int(h["exact"][0])
+        assert 0 < exact <= T and int(h["order"][0]) != -1
+        r = h["rank"].numpy()
+        assert r[0] >= 1 and bool((np.diff(r[:exact]) >= 1).all())
+        est = r[exact:].view(np.float64)
+        assert bool((est >= 2.0 ** 62).all()) and bool((np.diff(est) >= 0).all())
+        assert bool((np.diff(h["ml2p"].numpy()) >= 0).all())
+    last = host[(args.warmup + args.steps - 1) & 1]
+    assert np.array_equal(np.sort(last["order"].numpy().view(np.uint32)), np.arange(T, dtype=np.uint32))
+    assert np.array_equal(t_ml2p.cpu().numpy()[last["order"].numpy().view(np.uint32)], last["ml2p"].numpy())
+    sort_info = rk_last[0].check()
 
     if rank == 0:
         draws, probes = cnt["draws"] / args.steps, cnt["cdf_probes"] / args.steps
         indirect = cnt["indirect_draws"] / args.steps
         bytes_per_launch = draws * B_DRAW + indirect * B_INDIRECT + probes * B_PROBE + N * B_SAMPLE
         achieved = bytes_per_launch / (ms["sample"] * 1e-3) / 1e9
-        rank_bytes = N * (B_HIST + B_PASS * active + B_SCAN)
+        rank_bytes = N * B_RANK
+        gn_ms = ms["score"] + ms["order"] + ms["query"] + ms["guess_numbers"]
         rank_achieved = rank_bytes / (ms["rank"] * 1e-3) / 1e9
         out = {
             "metric": "sampled passwords/sec (node) + guess numbers/sec, 4-gram backoff, 1/2/4/8 GPU",
@@ -225,23 +273,30 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[1]: backwords char-level backoff (threshold 10, 100k synthetic Zipf "
                                    "training lines), 1e7 samples + 1e6 test pwds per GPU per step",
+                       "sort": "csrc/mc_sort.hip (heavy values counted, MSD radix on the rest, in-LDS finish; no "
+                               "workgroup waits for another)",
                        "samples_per_gpu": N, "test_pwds": T, "contexts": int(flat.info[nv.INFO_NCTX]),
                        "entries": int(flat.info[nv.INFO_NENT]), "table_bytes": int(flat.info[nv.INFO_DEVICE_BYTES])},
             "stage_ms": ms, "score_overlapped": side is not None,
             "sampling_only_per_s": N * world / (ms["sample"] * 1e-3),
-            "guess_numbers_per_s": T / ((ms["score"] + ms["query"]) * 1e-3),
+            # score + stable order + bisection + monotone guess numbers (device time of those four stages); the
+            # copy of ranks/order/scores to the host (`d2h` in stage_ms) runs beside the next step
+            "guess_numbers_per_s": T / (gn_ms * 1e-3),
+            "guess_numbers_per_s_with_d2h_serial": T / ((gn_ms + ms["d2h"]) * 1e-3),
+            "d2h_bytes_per_step": 20 * T + 8, "guess_numbers_within_int64": exact / T,
             "draws_per_sample": draws / N, "indirect_draws_per_draw": indirect / max(draws, 1),
             "threshold_compares_per_draw": probes / max(draws, 1),
             # the longest single launch; HBM traffic from profiles/*pmc_hbm_traffic.json (rocprofv3 --pmc)
             "roofline": {"bound": "hbm", "kernel": "k_sample", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC.get("k_sample"),
                          "bytes_per_launch": bytes_per_launch, "kernel_ms": ms["sample"]},
-            # the rank build as a whole (hist + onesweep passes + scan: 13 launches, timed together)
-            "roofline_rank_build": {"bound": "hbm", "kernel": "mc_rank_build (k_hist_all, k_onesweep x active "
-                                    "passes, k_weight_sums, k_positions)", "achieved": rank_achieved,
+            # the rank build as a whole (csrc/mc_sort.hip's launches + weight sums + positions, timed together)
+            # against the 40 B/key a sort-and-scan cannot do without
+            "roofline_rank_build": {"bound": "hbm", "kernel": "mc_rank_build (k_sniff, k_strip, k_scatter, k_count, "
+                                    "k_finish, k_fill, k_weight_sums, k_positions)", "achieved": rank_achieved,
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rank_achieved / HBM_PEAK_GBS,
                                     "traffic": TRAFFIC.get("mc_rank_build"), "bytes_per_launch": rank_bytes,
-                                    "active_passes": active, "kernel_ms": ms["rank"]},
+                                    "kernel_ms": ms["rank"], "sort": sort_info},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, test, args.cpu_samples or N)

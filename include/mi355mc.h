@@ -282,6 +282,14 @@ int64_t mc_lines_array(const mc_lines *l, int what, void *dst, size_t cap);
 int64_t mc_format_gc(const char *pwds_utf8, size_t bytes, uint64_t n, const double *mlp, const int64_t *appearance,
                      const int64_t *rank, const int64_t *cracked, const double *ratio, char *dst, size_t cap);
 
+/* The same lines with the passwords as the code points of mc_lines_ingest (MC_LINES_CPS, MC_LINES_OFF) and an
+ * order: row i is unique line order[i] (n rows).  len(cps) * 4 + 120 * n bytes are always enough.  A lone
+ * surrogate among the code points has no UTF-8 form: MC_ERR_ARG (the caller writes such a file with the
+ * reference's loop). */
+int64_t mc_format_gc_cps(const uint32_t *cps, const uint64_t *off, const uint32_t *order, uint64_t n,
+                         const double *mlp, const int64_t *appearance, const int64_t *rank, const int64_t *cracked,
+                         const double *ratio, char *dst, size_t cap);
+
 /* ---- device residency ---------------------------------------------------------------------*/
 /* Uploads the compiled table to GPU `device` (one hipMalloc arena). */
 int mc_model_upload(const mc_table *t, int device, mc_model **out);
@@ -406,6 +414,30 @@ int mc_rank_build_noalloc(const double *keys_in, uint64_t n, uint64_t n_global, 
  * reference's `1`, after summing shards). */
 int mc_rank_query(const double *keys_sorted, const double *positions, uint64_t n, const double *x, uint64_t t,
                   double *out_pos, uint64_t *out_cnt, void *stream);
+
+/* ---- the test set's side of guess-number estimation ----------------------------------------------*/
+/* Stable ascending order of t test passwords by -log2 p: what `sorted(..., key=lambda x: x[2])` at the end of
+ * MonteCarlo.parse_file (lib4mc/MonteCarloParent.py:68) and `need_resort` of ml2p_iter2gc
+ * (lib4mc/MonteCarloLib.py:43-45) compute on the host.  x (device, left untouched); outputs (device):
+ * x_sorted[t] and order[t] = index of the i-th password in that order, ties by index (Python's stable sort).
+ * Any doubles order as Python compares them (-0.0 == 0.0; a NaN, which no scoring kernel produces, goes to one
+ * of the ends).  t < 2^32 - 1.  If the key sort gives up on the device (csrc/mc_sort.hip: a table overflow), every
+ * order[i] is 0xFFFFFFFF and every x_sorted[i] NaN: never a wrong order. */
+size_t mc_order_workspace_bytes(uint64_t t);
+int mc_order_keys(const double *x, uint64_t t, double *x_sorted, uint32_t *order, void *workspace,
+                  size_t workspace_bytes, void *stream);
+/* The loop of ml2p_iter2gc (lib4mc/MonteCarloLib.py:47-55) over t passwords IN ASCENDING ORDER of -log2 p:
+ * estimate_i = pos[i] if cnt[i] > 0 else 1 (cnt == NULL: pos[i] > 0 decides, the sharded form where only the
+ * summed positions travel), rank_i = ceil(max(estimate_i, rank_{i-1} + (1 if add1 else 0))), rank_0 = 0.
+ * pos / cnt are what mc_rank_query returned (summed over shards).  out_rank[t] (device int64) is exact for the
+ * first *out_exact passwords (device uint64, written by the call): the reference computes in Python integers and
+ * guess numbers are not bounded by 2^63; estimates ascend, so what does not fit (ceil(estimate) >= 2^62, or a
+ * NaN) is a suffix, which the caller finishes from index *out_exact on with the reference's own expression
+ * (an unsorted input only makes that suffix start earlier): out_rank[i] for i >= *out_exact holds the fp64 bit
+ * pattern of estimate_i, so the one array carries all the caller needs. */
+size_t mc_guess_numbers_workspace_bytes(uint64_t t);
+int mc_guess_numbers(const double *pos, const uint64_t *cnt, uint64_t t, int add1, int64_t *out_rank,
+                     uint64_t *out_exact, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- threshold enumeration ------------------------------------------------------------------*/
 /* Replaces the recursive enumerators (nwords/nwords_enumerator.py:15-42 `enumerator`/`iterate` for a

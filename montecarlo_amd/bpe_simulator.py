@@ -108,14 +108,20 @@ class BpePcfgSim(MonteCarlo):
         ml2p = self._dev.score_bpe(cps, cls, off).cpu().numpy().tolist()
         return ml2p, [[p] for p in pwds]
 
+    def _score_unique_device(self, lines):
+        """parse_file's scoring on lines the native ingest encoded: the device vector of -log2 p."""
+        return self._dev.score_bpe(lines.cps, self._classes(lines.cps), lines.off)
+
     def encode(self, pwds: List[str]):
         """Passwords -> (code points, luds character classes, offsets) for mc_score_bpe."""
         cps, off, _ = self._flat.encode_text(pwds)
+        return cps, self._classes(cps), off
+
+    def _classes(self, cps: np.ndarray) -> np.ndarray:
         lut = self._cls_lut
         uniq = np.unique(cps)
         for c in uniq.tolist():
             if c not in lut:
                 lut[c] = char_class(chr(c))
         table = np.array([lut[c] for c in uniq.tolist()], dtype=np.uint8)
-        cls = table[np.searchsorted(uniq, cps)] if len(cps) else np.zeros(0, dtype=np.uint8)
-        return cps, cls, off
+        return table[np.searchsorted(uniq, cps)] if len(cps) else np.zeros(0, dtype=np.uint8)

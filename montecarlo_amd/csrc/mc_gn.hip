@@ -1,0 +1,266 @@
+// Guess numbers for a scored test set (gfx950): the parts of MonteCarlo.parse_file and
+// MonteCarloLib.ml2p_iter2gc that are per-password loops in the reference,
+//     lib4mc/MonteCarloParent.py:68    sorted(..., key=lambda x: x[2])              -> mc_order_keys
+//     lib4mc/MonteCarloLib.py:47-55    rank = ceil(max(estimate, prev_rank + add))  -> mc_guess_numbers
+//
+//   order     stable argsort of the test passwords' -log2 p with the keys-only sort of csrc/mc_sort.hip, twice:
+//             the keys (as words whose unsigned order is the doubles' order, both zeros alike) are sorted, every
+//             password looks up the index of the first key equal to its own, and the words (that index << 32 |
+//             password index) are sorted: their low halves are the order, ties by password index -- what
+//             Python's stable sort gives.
+//   ranks     in that order rank_i = max(ceil(est_i), rank_{i-1} + add) is i * add + a running maximum of
+//             ceil(est_i) - i * add: an inclusive max-scan in int64, exact while ceil(est) < 2^62.  Estimates
+//             ascend, so whatever lies beyond that (guess numbers reach 2^90 and more) is a suffix: the kernel
+//             reports where it starts and the host finishes it with Python integers, as the reference computes all.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "mc_internal.h"
+#include "mc_sort.h"
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            mc_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return MC_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+namespace {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+typedef long long i64;
+
+constexpr int GN_THREADS = 256, GN_ITEMS = 8, GN_TILE = GN_THREADS * GN_ITEMS, GN_MAX_BLOCKS = 1024;
+constexpr i64 GN_NEG = -(1ll << 62);
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// fp64 bits -> a word whose unsigned order is the numeric order (-0.0 and 0.0 compare equal in Python: one word)
+__device__ __forceinline__ u64 order_bits(u64 b) {
+    if ((b << 1) == 0) b = 0;
+    return (b >> 63) ? ~b : (b | (1ull << 63));
+}
+
+__global__ void __launch_bounds__(256) k_order_prep(const u64 *__restrict__ x, u64 t, u64 *__restrict__ keys) {
+    for (u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x; p < t; p += (u64)gridDim.x * blockDim.x)
+        keys[p] = order_bits(x[p]);
+}
+
+// words[p] = (index of the first sorted key equal to x[p]'s) << 32 | p
+__global__ void __launch_bounds__(256) k_order_words(const u64 *__restrict__ sorted, const u64 *__restrict__ x, u64 t,
+                                                     u64 *__restrict__ words, const u32 *sort_err, u32 *failed) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *failed = *sort_err;  // (the second sort clears the sort's own word)
+    for (u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x; p < t; p += (u64)gridDim.x * blockDim.x) {
+        const u64 v = order_bits(x[p]);
+        u64 lo = 0, hi = t;  // first index with sorted[i] >= v
+        while (lo < hi) {
+            const u64 mid = (lo + hi) >> 1;
+            if (sorted[mid] < v) lo = mid + 1; else hi = mid;
+        }
+        words[p] = (lo << 32) | p;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_order_out(const u64 *__restrict__ words, const u64 *__restrict__ x, u64 t,
+                                                   u32 *__restrict__ order, u64 *__restrict__ x_sorted,
+                                                   const u32 *sort_err, const u32 *failed) {
+    const bool bad = (*sort_err | *failed) != 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < t; i += (u64)gridDim.x * blockDim.x) {
+        if (bad) {  // a sort gave up: no order at all rather than a wrong one
+            order[i] = 0xFFFFFFFFu;
+            x_sorted[i] = 0x7FF8000000000000ull;
+            continue;
+        }
+        const u32 o = (u32)words[i];
+        order[i] = o;
+        x_sorted[i] = x[o];  // (the caller's own bits, signed zeros included)
+    }
+}
+
+// estimate_i = pos[i] if the bisection counted a sample, else 1 (lib4mc/MonteCarloLib.py:53)
+__device__ __forceinline__ double gn_estimate(const double *pos, const u64 *cnt, u64 i) {
+    const double p = pos[i];
+    return (cnt ? cnt[i] > 0 : p > 0.0) ? p : 1.0;
+}
+
+// ceil(est) - i * add as int64, or GN_NEG from the first estimate that does not fit (its index goes to *inexact)
+__device__ __forceinline__ i64 gn_term(const double *pos, const u64 *cnt, u64 i, int add1, u64 *inexact) {
+    const double c = ceil(gn_estimate(pos, cnt, i));
+    if (!(c < 4611686018427387904.0)) {  // >= 2^62, or NaN
+        atomicMin(inexact, i);
+        return GN_NEG;
+    }
+    const i64 v = (i64)c - (add1 ? (i64)(i + 1) : 0);
+    return v > 0 ? v : 0;  // (rank_0 = 0: the running maximum starts at 0)
+}
+
+__device__ __forceinline__ i64 block_max_scan_excl(i64 v, i64 *wave_tot, i64 &block_total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    i64 inc = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const i64 u = __shfl_up(inc, o);
+        if (lane >= o && u > inc) inc = u;
+    }
+    i64 excl = __shfl_up(inc, 1);
+    if (lane == 0) excl = GN_NEG;
+    __syncthreads();
+    if (lane == 63) wave_tot[wid] = inc;
+    __syncthreads();
+    i64 off = GN_NEG, tot = GN_NEG;
+    for (int w = 0; w < GN_THREADS / 64; ++w) {
+        const i64 tt = wave_tot[w];
+        if (w < wid && tt > off) off = tt;
+        if (tt > tot) tot = tt;
+    }
+    block_total = tot;
+    return off > excl ? off : excl;
+}
+
+__global__ void __launch_bounds__(GN_THREADS) k_gn_chunk_max(const double *__restrict__ pos, const u64 *__restrict__ cnt,
+                                                             u64 t, u64 chunk, int add1, i64 *__restrict__ partials,
+                                                             u64 *inexact) {
+    __shared__ i64 wave_tot[GN_THREADS / 64];
+    const u64 lo = (u64)blockIdx.x * chunk, hi = lo + chunk < t ? lo + chunk : t;
+    i64 m = GN_NEG;
+    for (u64 i = lo + threadIdx.x; i < hi; i += GN_THREADS) {
+        const i64 v = gn_term(pos, cnt, i, add1, inexact);
+        m = v > m ? v : m;
+    }
+    i64 tot;
+    (void)block_max_scan_excl(m, wave_tot, tot);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(GN_THREADS) k_gn_scan_partials(i64 *partials, u32 nb) {
+    __shared__ i64 wave_tot[GN_THREADS / 64];
+    const u32 per = (nb + GN_THREADS - 1) / GN_THREADS;
+    const u32 lo = threadIdx.x * per < nb ? threadIdx.x * per : nb, hi = lo + per < nb ? lo + per : nb;
+    i64 m = GN_NEG;
+    for (u32 i = lo; i < hi; ++i) m = partials[i] > m ? partials[i] : m;
+    i64 tot;
+    i64 run = block_max_scan_excl(m, wave_tot, tot);
+    for (u32 i = lo; i < hi; ++i) {
+        const i64 v = partials[i];
+        partials[i] = run;  // exclusive
+        run = v > run ? v : run;
+    }
+}
+
+__global__ void __launch_bounds__(GN_THREADS) k_gn_ranks(const double *__restrict__ pos, const u64 *__restrict__ cnt,
+                                                         u64 t, u64 chunk, int add1, const i64 *__restrict__ partials,
+                                                         u64 *inexact, i64 *__restrict__ rank) {
+    __shared__ i64 wave_tot[GN_THREADS / 64];
+    const u64 lo = (u64)blockIdx.x * chunk, hi = lo + chunk < t ? lo + chunk : t;
+    const u64 exact = *inexact;  // (final: k_gn_chunk_max has seen every term)
+    i64 carry = partials[blockIdx.x];
+    if (carry < 0) carry = 0;
+    for (u64 t0 = lo; t0 < hi; t0 += GN_TILE) {
+        // a lane scans GN_ITEMS consecutive terms
+        i64 v[GN_ITEMS];
+        i64 m = GN_NEG;
+#pragma unroll
+        for (int j = 0; j < GN_ITEMS; ++j) {
+            const u64 i = t0 + (u64)threadIdx.x * GN_ITEMS + j;
+            v[j] = i < hi ? gn_term(pos, cnt, i, add1, inexact) : GN_NEG;
+            m = v[j] > m ? v[j] : m;
+            v[j] = m;  // inclusive within the lane
+        }
+        i64 tot;
+        const i64 excl = block_max_scan_excl(m, wave_tot, tot);
+        const i64 before = excl > carry ? excl : carry;
+#pragma unroll
+        for (int j = 0; j < GN_ITEMS; ++j) {
+            const u64 i = t0 + (u64)threadIdx.x * GN_ITEMS + j;
+            if (i < hi) {
+                const i64 r = v[j] > before ? v[j] : before;
+                // from the first estimate beyond int64 on: the estimates themselves, for the caller's integers
+                rank[i] = i < exact ? r + (add1 ? (i64)(i + 1) : 0) : (i64)__double_as_longlong(gn_estimate(pos, cnt, i));
+            }
+        }
+        carry = tot > carry ? tot : carry;
+        __syncthreads();
+    }
+}
+
+__global__ void k_gn_init(u64 *inexact, u64 t) { *inexact = t; }
+
+}  // namespace
+
+extern "C" size_t mc_order_workspace_bytes(uint64_t t) {
+    return align256(mc_sort_workspace_bytes(t)) + 2 * align256(t * sizeof(u64)) + 256;
+}
+
+extern "C" int mc_order_keys(const double *x, uint64_t t, double *x_sorted, uint32_t *order, void *workspace,
+                             size_t workspace_bytes, void *stream) {
+    if (t == 0) return MC_OK;
+    if (!x || !x_sorted || !order || !workspace || (const void *)x == (const void *)x_sorted) {
+        mc_set_error("mc_order_keys: bad argument");
+        return MC_ERR_ARG;
+    }
+    if (t >= 0xFFFFFFFFull) {
+        mc_set_error("mc_order_keys: at most 2^32 - 2 keys (got %llu)", (unsigned long long)t);
+        return MC_ERR_ARG;
+    }
+    if (workspace_bytes < mc_order_workspace_bytes(t)) {
+        mc_set_error("mc_order_keys: workspace of %zu bytes, need %zu", workspace_bytes, mc_order_workspace_bytes(t));
+        return MC_ERR_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t sort_bytes = align256(mc_sort_workspace_bytes(t));
+    u64 *words = (u64 *)((char *)workspace + sort_bytes);
+    u64 *words_sorted = (u64 *)((char *)words + align256(t * sizeof(u64)));
+    u32 *failed = (u32 *)((char *)words_sorted + align256(t * sizeof(u64)));
+    uint32_t *err1 = nullptr, *err2 = nullptr;
+    const u32 g = (u32)((t + 255) / 256 < 2048 ? (t + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_order_prep, dim3(g), dim3(256), 0, s, (const u64 *)x, (u64)t, words_sorted);
+    int rc = mc_sort_keys((const uint64_t *)words_sorted, t, (uint64_t *)x_sorted, workspace, sort_bytes, &err1, 0, s);
+    if (rc != MC_OK) return rc;
+    hipLaunchKernelGGL(k_order_words, dim3(g), dim3(256), 0, s, (const u64 *)x_sorted, (const u64 *)x, (u64)t, words,
+                       (const u32 *)err1, failed);
+    rc = mc_sort_keys((const uint64_t *)words, t, (uint64_t *)words_sorted, workspace, sort_bytes, &err2, 0, s);
+    if (rc != MC_OK) return rc;
+    hipLaunchKernelGGL(k_order_out, dim3(g), dim3(256), 0, s, (const u64 *)words_sorted, (const u64 *)x, (u64)t, order,
+                       (u64 *)x_sorted, (const u32 *)err2, (const u32 *)failed);
+    HIP_TRY(hipGetLastError());
+    return MC_OK;
+}
+
+extern "C" size_t mc_guess_numbers_workspace_bytes(uint64_t t) {
+    (void)t;
+    return align256(GN_MAX_BLOCKS * sizeof(i64)) + 256;
+}
+
+extern "C" int mc_guess_numbers(const double *pos, const uint64_t *cnt, uint64_t t, int add1, int64_t *out_rank,
+                                uint64_t *out_exact, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!out_exact) {
+        mc_set_error("mc_guess_numbers: bad argument");
+        return MC_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_gn_init, dim3(1), dim3(1), 0, s, (u64 *)out_exact, (u64)t);
+    if (t == 0) return MC_OK;
+    if (!pos || !out_rank || !workspace) {
+        mc_set_error("mc_guess_numbers: bad argument");
+        return MC_ERR_ARG;
+    }
+    if (workspace_bytes < mc_guess_numbers_workspace_bytes(t)) {
+        mc_set_error("mc_guess_numbers: workspace of %zu bytes, need %zu", workspace_bytes,
+                     mc_guess_numbers_workspace_bytes(t));
+        return MC_ERR_WORKSPACE;
+    }
+    i64 *partials = (i64 *)workspace;
+    const u64 tiles = (t + GN_TILE - 1) / GN_TILE;
+    const u32 nb = (u32)(tiles < (u64)GN_MAX_BLOCKS ? tiles : (u64)GN_MAX_BLOCKS);
+    const u64 chunk = ((tiles + nb - 1) / nb) * GN_TILE;
+    hipLaunchKernelGGL(k_gn_chunk_max, dim3(nb), dim3(GN_THREADS), 0, s, pos, (const u64 *)cnt, (u64)t, chunk, add1,
+                       partials, (u64 *)out_exact);
+    hipLaunchKernelGGL(k_gn_scan_partials, dim3(1), dim3(GN_THREADS), 0, s, partials, nb);
+    hipLaunchKernelGGL(k_gn_ranks, dim3(nb), dim3(GN_THREADS), 0, s, pos, (const u64 *)cnt, (u64)t, chunk, add1,
+                       (const i64 *)partials, (u64 *)out_exact, (i64 *)out_rank);
+    HIP_TRY(hipGetLastError());
+    return MC_OK;
+}

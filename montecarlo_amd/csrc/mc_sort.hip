@@ -800,6 +800,44 @@ __global__ void __launch_bounds__(WG) k_scatter(Ws w, int level) {
 }
 
 // ---- finish tiles ---------------------------------------------------------------------------------------
+// A tile (<= CAP keys of the tail, all the keys of their value range) is ranked inside LDS.  A round spreads a
+// range of the tile over BINS linear buckets between its smallest and its largest key, in place; buckets of up to
+// SMALL_GROUP keys are ranked by counting; a larger bucket goes to one wave, which looks for the few distinct
+// values such a bucket usually holds (a value with tens to thousands of copies and a neighbour or two) and writes
+// their runs; a bucket that is not of that kind is sorted by the wave (compare-exchange network, up to WAVE_SORT
+// keys) or becomes the range of a later round, bucketed over ITS OWN smallest and largest key -- clustered keys
+// (a few far-apart groups, each dense) separate at the scale they have.  A round at least halves the key range of
+// what it passes on, so every range ends.
+constexpr int WAVE_SORT = 256;     // a bucket of up to this many keys is sorted by one wave
+constexpr int WL_CAP = 128;        // ranges waiting for a round (> WAVE_SORT keys each, disjoint per depth)
+constexpr int LARGE_CAP = CAP / SMALL_GROUP;
+constexpr int PROBE = 4;           // distinct values a wave looks for in a large bucket
+
+// ascending in-place sort of a[0..g) by one wave (g <= WAVE_SORT): the bitonic network in its one-direction form
+// (the first step of every merge pairs i with i ^ (2k - 1)), so that the missing keys of the last power of two
+// act as +infinity without being stored
+__device__ __forceinline__ void wave_sort(u64 *a, u32 g, int lane) {
+    u32 P = 64;
+    while (P < g) P <<= 1;
+    for (u32 k = 2; k <= P; k <<= 1) {
+        for (u32 j = k >> 1; j > 0; j >>= 1) {
+            const u32 mask = j == (k >> 1) ? k - 1 : j;
+            for (u32 i = lane; i < P; i += 64) {
+                const u32 l = i ^ mask;
+                if (l > i && l < g) {
+                    const u64 x = a[i], y = a[l];
+                    if (y < x) {
+                        a[i] = y;
+                        a[l] = x;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 __global__ void __launch_bounds__(WG) k_finish(Ws w) {
     __shared__ u64 stage[CAP];
     __shared__ u32 start[BINS + 1];
@@ -808,8 +846,9 @@ __global__ void __launch_bounds__(WG) k_finish(Ws w) {
     __shared__ u32 gapl[H_MAX + 1];
     __shared__ u32 wtot[NWAVE];
     __shared__ u64 red[2 * NWAVE];
-    __shared__ u32 large[2 * (CAP / SMALL_GROUP)];
-    __shared__ u32 nlarge;
+    __shared__ u32 large[2 * LARGE_CAP];
+    __shared__ u32 wl[2 * WL_CAP];
+    __shared__ u32 nlarge, nwl;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const u32 H = w.ctl->n_heavy;
     if (w.ctl->err) return;  // a table overflowed in an earlier kernel: the tile list is not to be trusted
@@ -851,150 +890,198 @@ __global__ void __launch_bounds__(WG) k_finish(Ws w) {
         const u64 *src = (f.src == SRC_IN ? w.in : (f.src == SRC_B ? (const u64 *)w.B : (const u64 *)w.C)) + f.off;
         u64 *out = w.A + f.off;
         const u64 room = (u64)w.n - f.off;  // a final index is < n; checked at every store
-        u64 k[ITEMS];
-        u64 mn = EMPTY, mx = 0;
-#pragma unroll
-        for (int q = 0; q < ITEMS; ++q) {
-            const u32 j = q * WG + tid;
-            k[q] = j < m ? src[j] : 0ull;
-            if (j < m) {
-                mn = k[q] < mn ? k[q] : mn;
-                mx = k[q] > mx ? k[q] : mx;
-            }
-        }
-        mn = wave_min(mn);
-        mx = wave_max(mx);
-        if (lane == 0) {
-            red[wid] = mn;
-            red[NWAVE + wid] = mx;
-        }
-        if (tid == 0) nlarge = 0;
-        __syncthreads();
-        mn = red[0];
-        mx = red[NWAVE];
-#pragma unroll
-        for (int i = 1; i < NWAVE; ++i) {
-            mn = red[i] < mn ? red[i] : mn;
-            mx = red[NWAVE + i] > mx ? red[NWAVE + i] : mx;
-        }
-        const u32 idx_lo = heavy_below(mn, 0, H), idx_hi = heavy_below(mx, idx_lo, H);
-        if (mn == mx) {  // one value: copy it to its place
-            const u32 shiftv = hp[idx_lo];
-#pragma unroll
-            for (int q = 0; q < ITEMS; ++q) {
-                const u32 j = q * WG + tid;
-                if (j < m) {
-                    if ((u64)j + shiftv < room) out[j + shiftv] = k[q]; else atomicOr(&w.ctl->err, ERR_RANGE);
-                }
-            }
-            __syncthreads();
-            if (tid == 0) gapl[idx_lo] += m;
-            continue;
-        }
-        // linear buckets over [mn, mx]: (key - mn) >> sh < BINS
-        const u64 range = mx - mn;
-        const int bl = 64 - __builtin_clzll(range);
-        const int sh = bl > 12 ? bl - 12 : 0;
-        for (int i = tid; i <= BINS; i += WG) start[i] = 0;
-        __syncthreads();
-        u32 rk[ITEMS];
-#pragma unroll
-        for (int q = 0; q < ITEMS; ++q) {
-            const u32 j = q * WG + tid;
-            rk[q] = j < m ? atomicAdd(&start[(u32)((k[q] - mn) >> sh)], 1u) : 0u;
-        }
-        __syncthreads();
-        {
-            u32 c[BINS / WG];
-            u32 s = 0;
-#pragma unroll
-            for (int q = 0; q < BINS / WG; ++q) {
-                c[q] = start[tid * (BINS / WG) + q];
-                s += c[q];
-            }
-            u32 tot;
-            u32 ex = wg_excl_scan(s, wtot, tot);
-#pragma unroll
-            for (int q = 0; q < BINS / WG; ++q) {
-                start[tid * (BINS / WG) + q] = ex;
-                ex += c[q];
-            }
-            if (tid == 0) start[BINS] = m;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < ITEMS; ++q) {
-            const u32 j = q * WG + tid;
-            if (j < m) stage[start[(u32)((k[q] - mn) >> sh)] + rk[q]] = k[q];
-        }
-        __syncthreads();
-#pragma unroll 1
-        for (int q = 0; q < ITEMS; ++q) {
-            const u32 j = q * WG + tid;
-            if (j >= m) break;
-            const u64 key = stage[j];
-            const u32 d = (u32)((key - mn) >> sh);
-            const u32 s = start[d], e = start[d + 1], g = e - s;
-            u32 pos = j;
-            if (g > (u32)SMALL_GROUP) {
-                if (j == s) {
-                    const u32 li = atomicAdd(&nlarge, 1u);
-                    large[2 * li] = s;
-                    large[2 * li + 1] = g;
-                }
-                continue;
-            }
-            if (g > 1) {
-                u32 r = 0;
-                for (u32 i = s; i < e; i += 4) {  // (four independent reads a step: the bucket is <= 32 keys)
-                    const u64 o0 = stage[i];
-                    const u64 o1 = stage[i + 1 < e ? i + 1 : i];
-                    const u64 o2 = stage[i + 2 < e ? i + 2 : i];
-                    const u64 o3 = stage[i + 3 < e ? i + 3 : i];
-                    r += (o0 < key || (o0 == key && i < j)) ? 1u : 0u;
-                    r += (i + 1 < e && (o1 < key || (o1 == key && i + 1 < j))) ? 1u : 0u;
-                    r += (i + 2 < e && (o2 < key || (o2 == key && i + 2 < j))) ? 1u : 0u;
-                    r += (i + 3 < e && (o3 < key || (o3 == key && i + 3 < j))) ? 1u : 0u;
-                }
-                pos = s + r;
-            }
+        u32 idx_lo = 0, idx_hi = 0;         // heavy values below the tile's smallest / largest key
+        // `pos` = the key's rank inside the tile; its place in A adds the copies of the heavy values below it
+        auto emit = [&](u32 pos, u64 key) {
             const u32 hidx = idx_lo == idx_hi ? idx_lo : heavy_below(key, idx_lo, idx_hi);
             const u64 at = (u64)pos + hp[hidx];
             if (at < room) out[at] = key; else atomicOr(&w.ctl->err, ERR_RANGE);
             if (idx_lo != idx_hi) atomicAdd(&gapl[hidx], 1u);
-        }
-        __syncthreads();
-        // large buckets: a wave walks the bucket's distinct values in ascending order (a repeated value and
-        // a few neighbours, typically); the bucket's keys all lie within range / BINS of each other
-        const u32 nl = nlarge;
-        for (u32 li = wid; li < nl; li += NWAVE) {
-            const u32 s = large[2 * li], g = large[2 * li + 1];
-            u32 placed = 0;
-            u64 last = 0;
-            bool have_last = false;
-            while (placed < g) {
-                u64 cand = EMPTY;
-                for (u32 i = lane; i < g; i += 64) {
-                    const u64 v = stage[s + i];
-                    if ((!have_last || v > last) && v < cand) cand = v;
-                }
-                cand = wave_min(cand);
-                u32 c = 0;
-                for (u32 i = lane; i < g; i += 64) c += stage[s + i] == cand ? 1u : 0u;
-                c = wave_sum(c);
-                if (c == 0) break;  // (cannot happen; guards the loop)
-                const u32 hidx = idx_lo == idx_hi ? idx_lo : heavy_below(cand, idx_lo, idx_hi);
-                const u64 at0 = (u64)s + placed + hp[hidx];
-                for (u32 i = lane; i < c; i += 64) {
-                    if (at0 + i < room) out[at0 + i] = cand; else atomicOr(&w.ctl->err, ERR_RANGE);
-                }
-                if (lane == 0 && idx_lo != idx_hi) atomicAdd(&gapl[hidx], c);
-                placed += c;
-                last = cand;
-                have_last = true;
+        };
+        auto emit_run = [&](u32 pos, u64 key, u32 c, int ln, int step) {  // c copies of key from rank pos on
+            const u32 hidx = idx_lo == idx_hi ? idx_lo : heavy_below(key, idx_lo, idx_hi);
+            const u64 at0 = (u64)pos + hp[hidx];
+            for (u32 i = ln; i < c; i += step) {
+                if (at0 + i < room) out[at0 + i] = key; else atomicOr(&w.ctl->err, ERR_RANGE);
             }
+            if (ln == 0 && idx_lo != idx_hi) atomicAdd(&gapl[hidx], c);
+        };
+        if (tid == 0) {
+            nlarge = 0;
+            nwl = 1;
+            wl[0] = 0;
+            wl[1] = m;
         }
-        __syncthreads();
+        for (u32 r = 0;; ++r) {
+            __syncthreads();
+            if (r >= nwl || r >= (u32)WL_CAP) break;
+            const u32 s0 = wl[2 * r], g0 = wl[2 * r + 1];
+            u64 k[ITEMS];
+            u64 mn = EMPTY, mx = 0;
+#pragma unroll
+            for (int q = 0; q < ITEMS; ++q) {
+                const u32 j = q * WG + tid;
+                k[q] = j < g0 ? (r == 0 ? src[j] : stage[s0 + j]) : 0ull;
+                if (j < g0) {
+                    mn = k[q] < mn ? k[q] : mn;
+                    mx = k[q] > mx ? k[q] : mx;
+                }
+            }
+            mn = wave_min(mn);
+            mx = wave_max(mx);
+            if (lane == 0) {
+                red[wid] = mn;
+                red[NWAVE + wid] = mx;
+            }
+            __syncthreads();
+            mn = red[0];
+            mx = red[NWAVE];
+#pragma unroll
+            for (int i = 1; i < NWAVE; ++i) {
+                mn = red[i] < mn ? red[i] : mn;
+                mx = red[NWAVE + i] > mx ? red[NWAVE + i] : mx;
+            }
+            if (r == 0) {
+                idx_lo = heavy_below(mn, 0, H);
+                idx_hi = heavy_below(mx, idx_lo, H);
+            }
+            if (mn == mx) {  // one value: a run
+                emit_run(s0, mn, g0, tid, WG);
+                continue;
+            }
+            // linear buckets over [mn, mx]: (key - mn) >> sh < BINS
+            const u64 range = mx - mn;
+            const int bl = 64 - __builtin_clzll(range);
+            const int sh = bl > 12 ? bl - 12 : 0;
+            for (int i = tid; i <= BINS; i += WG) start[i] = 0;
+            __syncthreads();
+            u32 rk[ITEMS];
+#pragma unroll
+            for (int q = 0; q < ITEMS; ++q) {
+                const u32 j = q * WG + tid;
+                rk[q] = j < g0 ? atomicAdd(&start[(u32)((k[q] - mn) >> sh)], 1u) : 0u;
+            }
+            __syncthreads();
+            {
+                u32 c[BINS / WG];
+                u32 s = 0;
+#pragma unroll
+                for (int q = 0; q < BINS / WG; ++q) {
+                    c[q] = start[tid * (BINS / WG) + q];
+                    s += c[q];
+                }
+                u32 tot;
+                u32 ex = wg_excl_scan(s, wtot, tot);
+#pragma unroll
+                for (int q = 0; q < BINS / WG; ++q) {
+                    start[tid * (BINS / WG) + q] = ex;
+                    ex += c[q];
+                }
+                if (tid == 0) start[BINS] = g0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < ITEMS; ++q) {  // (in place: every key of the range is in a register)
+                const u32 j = q * WG + tid;
+                if (j < g0) stage[s0 + start[(u32)((k[q] - mn) >> sh)] + rk[q]] = k[q];
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int q = 0; q < ITEMS; ++q) {
+                const u32 j = q * WG + tid;
+                if (j >= g0) break;
+                const u64 *st = stage + s0;
+                const u64 key = st[j];
+                const u32 d = (u32)((key - mn) >> sh);
+                const u32 s = start[d], e = start[d + 1], g = e - s;
+                u32 pos = j;
+                if (g > (u32)SMALL_GROUP) {
+                    if (j == s) {
+                        const u32 li = atomicAdd(&nlarge, 1u);
+                        if (li < (u32)LARGE_CAP) {
+                            large[2 * li] = s0 + s;
+                            large[2 * li + 1] = g;
+                        } else {
+                            atomicOr(&w.ctl->err, ERR_RANGE);  // (more than CAP / SMALL_GROUP such buckets: impossible)
+                        }
+                    }
+                    continue;
+                }
+                if (g > 1) {
+                    u32 rr = 0;
+                    for (u32 i = s; i < e; i += 4) {  // (four independent reads a step)
+                        const u64 o0 = st[i];
+                        const u64 o1 = st[i + 1 < e ? i + 1 : i];
+                        const u64 o2 = st[i + 2 < e ? i + 2 : i];
+                        const u64 o3 = st[i + 3 < e ? i + 3 : i];
+                        rr += (o0 < key || (o0 == key && i < j)) ? 1u : 0u;
+                        rr += (i + 1 < e && (o1 < key || (o1 == key && i + 1 < j))) ? 1u : 0u;
+                        rr += (i + 2 < e && (o2 < key || (o2 == key && i + 2 < j))) ? 1u : 0u;
+                        rr += (i + 3 < e && (o3 < key || (o3 == key && i + 3 < j))) ? 1u : 0u;
+                    }
+                    pos = s + rr;
+                }
+                emit(s0 + pos, key);
+            }
+            __syncthreads();
+            // this round's large buckets, a wave each
+            const u32 nl = nlarge < (u32)LARGE_CAP ? nlarge : (u32)LARGE_CAP;
+            for (u32 li = wid; li < nl; li += NWAVE) {
+                const u32 s = large[2 * li], g = large[2 * li + 1];
+                // the PROBE smallest distinct values and their copies -- nothing is written until they are known
+                // to be all there is
+                u64 cand[PROBE];
+                u32 cc[PROBE];
+                u32 found = 0, placed = 0;
+                u64 last = 0;
+                bool go = true;
+#pragma unroll
+                for (int it = 0; it < PROBE; ++it) {
+                    cand[it] = EMPTY;
+                    cc[it] = 0;
+                    if (it == 2 && placed * 2 < g) go = false;  // (two values and not half the bucket: give up)
+                    if (go && placed < g) {
+                        u64 c0 = EMPTY;
+                        for (u32 i = lane; i < g; i += 64) {
+                            const u64 v = stage[s + i];
+                            if ((it == 0 || v > last) && v < c0) c0 = v;
+                        }
+                        c0 = wave_min(c0);
+                        u32 c = 0;
+                        for (u32 i = lane; i < g; i += 64) c += stage[s + i] == c0 ? 1u : 0u;
+                        c = wave_sum(c);
+                        cand[it] = c0;
+                        cc[it] = c;
+                        placed += c;
+                        last = c0;
+                        found = it + 1;
+                    }
+                }
+                if (placed == g) {
+                    u32 at = s;
+#pragma unroll
+                    for (int it = 0; it < PROBE; ++it) {
+                        if (it < (int)found) {
+                            emit_run(at, cand[it], cc[it], lane, 64);
+                            at += cc[it];
+                        }
+                    }
+                } else if (g <= (u32)WAVE_SORT) {
+                    wave_sort(stage + s, g, lane);
+                    for (u32 i = lane; i < g; i += 64) emit(s + i, stage[s + i]);
+                } else if (lane == 0) {
+                    const u32 wi = atomicAdd(&nwl, 1u);
+                    if (wi < (u32)WL_CAP) {
+                        wl[2 * wi] = s;
+                        wl[2 * wi + 1] = g;
+                    } else {
+                        atomicOr(&w.ctl->err, ERR_RANGE);  // (deeper than 64-bit keys can nest: impossible)
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid == 0) nlarge = 0;
+        }
         // (no heavy value inside the tile's range: all its keys have the same number of heavy values below)
         if (idx_lo == idx_hi && tid == 0) gapl[idx_lo] += m;
     }

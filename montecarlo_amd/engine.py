@@ -215,5 +215,45 @@ class DeviceRank:
         return pos, cnt
 
 
+def device_order(x: torch.Tensor, out_sorted: torch.Tensor = None, out_order: torch.Tensor = None,
+                 workspace: torch.Tensor = None):
+    """Stable ascending order of the keys ``x`` (device float64): (sorted keys, order as int32 holding uint32
+    indices) -- mc_order_keys, what ``sorted(..., key=ml2p)`` of parse_file computes on the host.  With a
+    ``workspace`` of the caller's (mc_order_workspace_bytes) nothing is allocated and nothing waited for: the
+    caller checks ``order[0] != -1`` (the device's failure mark) once it has the result."""
+    _require_gpu()
+    assert x.is_cuda and x.dtype == torch.float64 and x.is_contiguous()
+    t = x.numel()
+    with torch.cuda.device(x.device):
+        srt = out_sorted if out_sorted is not None else torch.empty_like(x)
+        order = out_order if out_order is not None else torch.empty(t, dtype=torch.int32, device=x.device)
+        if t:
+            ws = workspace if workspace is not None else torch.empty(nv.lib.mc_order_workspace_bytes(t),
+                                                                     dtype=torch.uint8, device=x.device)
+            nv.check(nv.lib.mc_order_keys(_vp(x), t, _vp(srt), _vp(order), _vp(ws), ws.numel(),
+                                          C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+            if workspace is None:
+                torch.cuda.current_stream(x.device).synchronize()    # the workspace must outlive the kernels
+                if int(order[0]) == -1:
+                    raise nv.NativeError("mc_order_keys: the key sort reported an error on the device (no order "
+                                         "produced)")
+    return srt, order
+
+
+def device_guess_numbers(pos: torch.Tensor, cnt: Optional[torch.Tensor], add1: bool = True,
+                         out: torch.Tensor = None, workspace: torch.Tensor = None, exact: torch.Tensor = None):
+    """mc_guess_numbers on device vectors in ascending order of -log2 p: (ranks int64, exact) where ``exact`` is a
+    one-element device tensor = the number of leading ranks that are exact (the rest exceed int64)."""
+    t = pos.numel()
+    with torch.cuda.device(pos.device):
+        ranks = out if out is not None else torch.empty(t, dtype=torch.int64, device=pos.device)
+        ex = exact if exact is not None else torch.empty(1, dtype=torch.int64, device=pos.device)
+        ws = workspace if workspace is not None else torch.empty(nv.lib.mc_guess_numbers_workspace_bytes(t),
+                                                                 dtype=torch.uint8, device=pos.device)
+        nv.check(nv.lib.mc_guess_numbers(_vp(pos), _vp(cnt), t, 1 if add1 else 0, _vp(ranks), _vp(ex), _vp(ws),
+                                         ws.numel(), C.c_void_p(torch.cuda.current_stream(pos.device).cuda_stream)))
+    return ranks, ex, ws
+
+
 def log2_n(n: int) -> float:
     return math.log2(n)

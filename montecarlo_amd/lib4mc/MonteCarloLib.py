@@ -14,7 +14,7 @@ import numpy
 import torch
 
 from ..engine import DeviceRank
-from .MonteCarloParent import SampleKeys, gc_paused
+from .MonteCarloParent import SampleKeys
 
 
 class MonteCarloLib:
@@ -40,7 +40,6 @@ class MonteCarloLib:
         elif isinstance(minus_log_prob_list, list):
             minus_log_prob_list[:] = self.__rank.keys_sorted.cpu().numpy().tolist()
         self.__gc = None
-        self.__cols = None
 
     @property
     def device_rank(self) -> DeviceRank:
@@ -68,51 +67,84 @@ class MonteCarloLib:
     def ml2p_iter2gc(self, minus_log_prob_iter: List[Tuple[str, int, float]],
                      need_resort: bool = False, add1: bool = True) \
             -> List[Tuple[str, float, int, int, int, float]]:
-        if need_resort:
-            minus_log_prob_iter = sorted(minus_log_prob_iter, key=lambda x: x[2])
-        items = list(minus_log_prob_iter)
-        self.__cols = None
-        if not items:
+        """Reference :34-58.  The bisection, the monotone guess numbers and the running crack counts are computed
+        on columns (the first two on the GPU: mc_rank_query, mc_guess_numbers); the result behaves as the list of
+        tuples the reference returns and builds them only when looked at (montecarlo_amd.columns.GcList)."""
+        from ..columns import GcList, ScoredList
+        scored = minus_log_prob_iter
+        if not (isinstance(scored, ScoredList) and scored.pristine):
+            items = list(minus_log_prob_iter)
+            if need_resort:
+                items = sorted(items, key=lambda x: x[2])
+            n = len(items)
+            scored = ScoredList(order=None, count=_int_column([t[1] for t in items]),
+                                ml2p=numpy.fromiter((t[2] for t in items), dtype=numpy.float64, count=n),
+                                first=[t[0] for t in items],
+                                passwords=all(type(t[0]) is str for t in items[:1]))
+        # (a pristine parse_file result is in ascending order already: a stable resort would change nothing)
+        if len(scored) == 0:
             self.__gc = []
             return self.__gc
-        with gc_paused():
-            return self.__columns(items, add1)
-
-    def __columns(self, items, add1: bool):
-        pwds, apps, mlps = [t[0] for t in items], [t[1] for t in items], [t[2] for t in items]
-        pos, cnt = self.__estimates(mlps)
-        est = numpy.where(cnt > 0, pos, 1.0)
-        ranks = _monotone_ranks(est, cnt, add1)
-        total = sum(apps)
-        try:
-            running = numpy.cumsum(numpy.asarray(apps, dtype=numpy.int64))
-            exact = total < 2 ** 53 and running.size == len(apps)
-        except (OverflowError, TypeError, ValueError):
-            exact = False
-        if exact:
-            # c / total * 100 with both ints below 2^53: numpy's float64 division gives Python's quotient
-            ratio = running / float(total) * 100
-            cracked = running.tolist()
-            gc = list(zip(pwds, mlps, apps, ranks, cracked, ratio.tolist()))
-            # the columns write2 formats, kept while the list it returns is the one write2 sees
-            self.__cols = (pwds, numpy.asarray(mlps, dtype=numpy.float64), numpy.asarray(apps, dtype=numpy.int64),
-                           ranks, running, ratio)
-        else:
+        ranks = self.__guess_numbers(scored.ml2p, add1)
+        apps = scored.count
+        if apps.dtype == object:
             cracked, run = [], 0
-            for a in apps:
+            for a in apps.tolist():
                 run += a
                 cracked.append(run)
-            gc = [(p, m, a, r, c, c / total * 100) for p, m, a, r, c in zip(pwds, mlps, apps, ranks, cracked)]
-        self.__gc = gc
-        return gc
+            total = run
+            cracked = numpy.array(cracked, dtype=object)
+            ratio = numpy.array([c / total * 100 for c in cracked.tolist()], dtype=numpy.float64)
+        else:
+            cracked = numpy.cumsum(apps, dtype=numpy.int64)
+            total = int(cracked[-1])
+            if total < 2 ** 53:
+                # c / total * 100 with both ints below 2^53: numpy's float64 division gives Python's quotient.
+                # (Two statements on purpose: `cracked / t * 100` lets numpy try to reuse the temporary, for which
+                # it walks the C stack -- the first such walk in a process with the ROCm libraries loaded costs 80 ms.)
+                ratio = cracked / float(total)
+                numpy.multiply(ratio, 100, out=ratio)
+            else:
+                ratio = numpy.array([c / total * 100 for c in cracked.tolist()], dtype=numpy.float64)
+        self.__gc = GcList(scored, ranks, cracked, ratio)
+        return self.__gc
+
+    def __guess_numbers(self, mlps: numpy.ndarray, add1: bool):
+        """rank_i = ceil(max(estimate_i, rank_{i-1} + add)), rank_0 = 0 (reference :47-55), in the order given:
+        int64 array from the device (mc_guess_numbers), or a list of Python ints when some guess number
+        exceeds int64 -- those, a suffix in ascending order, are finished with the reference's own expression."""
+        from ..engine import device_guess_numbers
+        rk = self.__rank
+        x = torch.from_numpy(numpy.ascontiguousarray(mlps, dtype=numpy.float64)).to(rk.tdev)
+        pos, cnt = rk.query(x)
+        if self.__group is not None:
+            # every weight is positive: the summed position is > 0 exactly when some shard counted a sample
+            torch.distributed.all_reduce(pos, group=self.__group)
+            cnt = None
+        ranks_d, exact_d, _ws = device_guess_numbers(pos, cnt, add1)
+        ranks = ranks_d.cpu().numpy()
+        exact = int(exact_d.item())
+        if exact >= len(mlps):
+            return ranks
+        # what follows does not fit int64 (or is NaN): the kernel left the estimates there, as fp64 bit patterns
+        est = ranks[exact:].view(numpy.float64)
+        if numpy.isnan(est).any() and not numpy.isnan(mlps).any():
+            # a failed build poisons positions with NaN (on any shard: NaN survives the sum); never a guess number
+            raise RuntimeError("rank estimation failed: positions contain NaN (mc_rank_build reported an error "
+                               "on this device or on another shard)")
+        out = ranks[:exact].tolist()
+        prev, step = (out[-1] if out else 0), (1 if add1 else 0)
+        for e in est.tolist():
+            prev = ceil(max(e, prev + step))
+            out.append(prev)
+        return out
 
     def write2(self, fd: TextIO):
         if not fd.writable():
             raise Exception(f"{fd.name} is not writable")
         if self.__gc is None:
             raise Exception(f"run mlps2gc before invoke this method")
-        text = _format_native(self.__gc, self.__cols)
-        self.__cols = None
+        text = _format_native(self.__gc)
         if text is not None:
             fd.write(text)
         else:
@@ -121,23 +153,36 @@ class MonteCarloLib:
         self.__gc = None
 
 
-def _format_native(gc, cols=None) -> "str | None":
-    """write2's lines through mc_format_gc (csrc/mc_ingest.cpp), or None when a row is not what it takes
-    (a components list instead of a string, a guess number beyond int64, a newline inside a password):
-    the f-string loop then writes them, as the reference does.  ``cols``: the columns ml2p_iter2gc
-    kept, used when the list still is the one it returned (same length, same first / middle / last row)."""
+def _int_column(values) -> numpy.ndarray:
+    try:
+        a = numpy.asarray(values)
+        if a.dtype.kind in "iu" and a.ndim == 1:
+            return a.astype(numpy.int64)
+    except (OverflowError, TypeError, ValueError):
+        pass
+    return numpy.array(values, dtype=object)
+
+
+def _format_native(gc) -> "str | None":
+    """write2's lines through the native writers (csrc/mc_ingest.cpp), or None when a row is not what they take
+    (a components list instead of a string, a guess number beyond int64, a newline or a lone surrogate inside a
+    password, NaN): the f-string loop then writes them, as the reference does.  A pristine GcList is formatted
+    from its columns; when its passwords still are the code points of the ingest (parse_file's result went
+    straight through), no Python string is built for them at all."""
     import ctypes as C
 
     from .. import _native as nv
+    from ..columns import GcList
     n = len(gc)
     if n < 512:
         return None
-    fresh = cols is not None and len(cols[0]) == n and all(
-        gc[i][0] is cols[0][i] and gc[i][3] == cols[3][i] and gc[i][1] == cols[1][i] for i in (0, n // 2, n - 1))
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    cols = isinstance(gc, GcList) and gc.pristine and gc.scored.pristine and isinstance(gc.ranks, numpy.ndarray) \
+        and gc.scored.passwords and gc.scored.count.dtype != object and gc.cracked.dtype != object
     try:
-        if fresh:
-            pwds, mlp, apps, ranks, crk, ratio = cols
-            rank = numpy.asarray(ranks, dtype=numpy.int64)
+        if cols:
+            sc = gc.scored
+            mlp, apps, rank, crk, ratio = sc.ml2p, sc.count, gc.ranks, gc.cracked, gc.ratio
         else:
             pwds = [row[0] for row in gc]
             rank = numpy.fromiter((row[3] for row in gc), dtype=numpy.int64, count=n)
@@ -145,39 +190,35 @@ def _format_native(gc, cols=None) -> "str | None":
             crk = numpy.fromiter((row[4] for row in gc), dtype=numpy.int64, count=n)
             mlp = numpy.fromiter((row[1] for row in gc), dtype=numpy.float64, count=n)
             ratio = numpy.fromiter((row[5] for row in gc), dtype=numpy.float64, count=n)
-        if not all(type(p) is str for p in pwds):
-            return None
-        blob = "\n".join(pwds).encode("utf-8")                 # (lone surrogates: not UTF-8, take the loop)
-    except (UnicodeEncodeError, OverflowError, TypeError, ValueError):
-        return None
-    if blob.count(b"\n") != n - 1:
+    except (OverflowError, TypeError, ValueError):
         return None
     if not (numpy.isfinite(mlp).all() and numpy.isfinite(ratio).all()):
         return None                                            # (C prints a NaN's sign, Python does not)
     if float(numpy.abs(mlp).max()) >= 1e18 or float(numpy.abs(ratio).max()) >= 1e9:
         return None                                            # (wider than the native writer's 120 characters)
-    mlp, apps, rank, crk, ratio = (numpy.ascontiguousarray(x) for x in (mlp, apps, rank, crk, ratio))
+    mlp, apps, rank, crk, ratio = (numpy.ascontiguousarray(x) for x in (mlp, apps.astype(numpy.int64, copy=False),
+                                                                         rank, crk.astype(numpy.int64, copy=False),
+                                                                         ratio))
+    if cols and gc.scored.lines is not None and gc.scored._first is None:
+        lines = gc.scored.lines
+        order = numpy.ascontiguousarray(gc.scored.order, dtype=numpy.uint32)
+        out = numpy.empty(4 * len(lines.cps) + 120 * n, dtype=numpy.uint8)       # (not zero-filled)
+        size = nv.lib.mc_format_gc_cps(vp(lines.cps), vp(lines.off), vp(order), n, vp(mlp), vp(apps), vp(rank),
+                                       vp(crk), vp(ratio), vp(out), out.size)
+        if size >= 0:
+            return str(memoryview(out)[:size], "utf-8")
+        return None                                            # (a lone surrogate: the loop writes it as Python would)
+    if cols:
+        pwds = gc.scored.first_column()
+    try:
+        if not all(type(p) is str for p in pwds):
+            return None
+        blob = "\n".join(pwds).encode("utf-8")                 # (lone surrogates: not UTF-8, take the loop)
+    except (UnicodeEncodeError, TypeError):
+        return None
+    if blob.count(b"\n") != n - 1:
+        return None
     out = numpy.empty(len(blob) + 120 * n, dtype=numpy.uint8)           # (not zero-filled)
-    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
     size = nv.check(nv.lib.mc_format_gc(blob, len(blob), n, vp(mlp), vp(apps), vp(rank), vp(crk), vp(ratio),
                                         vp(out), out.size))
     return str(memoryview(out)[:size], "utf-8")
-
-
-def _monotone_ranks(est: numpy.ndarray, cnt: numpy.ndarray, add1: bool) -> List[int]:
-    """rank_i = ceil(max(est_i, rank_{i-1} + add)), rank_0 = 0 (reference :47-55).
-    While every value is below 2^52 (float and int comparisons exact) this is a running
-    maximum; beyond that it is evaluated with the reference's own expression, whose
-    numpy-float-vs-int comparisons are themselves lossy there."""
-    if est.size and numpy.all(numpy.isfinite(est)) and float(est.max()) < 2.0 ** 52:
-        c = numpy.ceil(est).astype(numpy.int64)
-        if add1:
-            i = numpy.arange(1, c.size + 1, dtype=numpy.int64)
-            s = numpy.maximum.accumulate(numpy.maximum(c - i, 0))
-            return (s + i).tolist()
-        return numpy.maximum.accumulate(numpy.maximum(c, 0)).tolist()
-    out, prev, step = [], 0, 1 if add1 else 0
-    for e, k in zip(est, cnt):
-        prev = ceil(max(e if k > 0 else 1, prev + step))
-        out.append(prev)
-    return out

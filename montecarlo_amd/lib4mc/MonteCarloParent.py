@@ -202,6 +202,11 @@ class MonteCarlo(metaclass=abc.ABCMeta):
     def _score_unique(self, lines, pwds: List[str], want_parts: bool):
         return self.score_batch(pwds)
 
+    def _score_unique_device(self, lines):
+        """-log2 p of ``lines`` (montecarlo_amd.ingest.UniqueLines) as a device float64 vector, or None when
+        the model scores through ``score_batch`` only (a third-party subclass)."""
+        return None
+
     def parse_file(self, testing_set: TextIO, using_component: bool = False) \
             -> List[Tuple[Union[str, List[str]], int, float]]:
         if self._flat is not None and testing_set.seekable():
@@ -211,14 +216,23 @@ class MonteCarlo(metaclass=abc.ABCMeta):
                 # every newline mode of a text file splits such a text at '\n' only: the native line
                 # counter sees what iterating the file would (a text with '\r' in it goes below)
                 from ..ingest import UniqueLines
+                from ..columns import ScoredList
                 lines = UniqueLines(text)
+                keys = self._score_unique_device(lines) if not using_component and len(lines) else None
+                if keys is not None:
+                    # scores stay on the GPU until they are sorted (mc_order_keys: Python's stable sort by
+                    # ml2p); the passwords stay code points until somebody reads a row
+                    from ..engine import device_order
+                    ml2p_d, order_d = device_order(keys.contiguous())
+                    order = order_d.cpu().numpy().view(np.uint32)
+                    return ScoredList(order, lines.count[order].astype(np.int64), ml2p_d.cpu().numpy(), lines=lines)
                 pwds = lines.strings()
                 ml2p, parts = self._score_unique(lines, pwds, using_component)
-                order = np.argsort(np.asarray(ml2p, dtype=np.float64), kind="stable").tolist()
+                ml2p = np.asarray(ml2p, dtype=np.float64)
+                order = np.argsort(ml2p, kind="stable")
                 first = parts if using_component else pwds
-                count = lines.count.tolist()
-                with gc_paused():
-                    return [(first[i], count[i], ml2p[i]) for i in order]
+                return ScoredList(order.astype(np.uint32), lines.count[order].astype(np.int64), ml2p[order],
+                                  first=[first[i] for i in order.tolist()], passwords=not using_component)
         wc_l(testing_set)                                   # rewinds, as the reference does
         counts: Dict[str, int] = {}
         for line in testing_set:

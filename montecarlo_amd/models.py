@@ -55,6 +55,16 @@ class TableBacked:
             return self._score_chars(pwds, self._flat.char_lut()[lines.cps], lines.off, want_parts)
         return self._score_words(pwds, lines.cps, lines.off, lines.longest, want_parts)
 
+    def _score_unique_device(self, lines):
+        """-log2 p of the ingest's unique lines as a device vector (parse_file without components: nothing
+        but the order and the sorted keys ever comes back to the host)."""
+        if not self._flat.multichar:
+            return self._dev.score_ids(self._flat.char_lut()[lines.cps], lines.off)
+        res, _ = self._dev.score_words(lines.cps, lines.off, lines.longest, getattr(self, "max_iter", 10 ** 35),
+                                       want_split=False)
+        self._dev.check()
+        return res
+
     def _score_chars(self, pwds, syms, off, want_parts: bool):
         # single-character alphabets have exactly one parse: the lookup-chain kernel
         end = self.end_chr

@@ -52,3 +52,6 @@ class NWords2MonteCarlo(TableBacked, MonteCarlo):
 
     def _score_unique(self, lines, pwds, want_parts):
         return self.score_batch(pwds)
+
+    def _score_unique_device(self, lines):
+        return self.score_batch(None)

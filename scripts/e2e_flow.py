@@ -28,3 +28,6 @@ scored = m.parse_file(fd); lap(f"parse_file({T} lines)")
 gc = mc.ml2p_iter2gc(scored); lap("ml2p_iter2gc")
 buf = io.StringIO(); mc.write2(buf); lap("write2")
 print("unique test pwds", len(scored), "output bytes", len(buf.getvalue()))
+t0 = t[-4]
+print(f"parse_file + ml2p_iter2gc + write2: {t[-1] - t0:.3f} s; tuples built: "
+      f"{scored._rows is not None or gc._rows is not None}", flush=True)

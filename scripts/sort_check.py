@@ -63,6 +63,12 @@ def main():
         "runs": torch.repeat_interleave(torch.rand(n // 1000 + 1, generator=g, dtype=torch.float64) * 90, 1000)[:n],
         "clusters": (torch.randint(0, 3, (n,), generator=g).double() * 16 + 5
                      + torch.randint(0, 1 << 20, (n,), generator=g).double() * 2.0 ** -45),
+        "nested clusters": ((torch.randint(0, 5, (n,), generator=g) << 50) + (torch.randint(0, 7, (n,), generator=g) << 25)
+                            + torch.randint(0, 1 << 12, (n,), generator=g) + (1 << 60)).view(torch.float64),
+        "order words": ((torch.randint(0, 300, (n,), generator=g) ** 2 << 32) + torch.arange(n) + (1 << 52))
+        .view(torch.float64),
+        "geometric": ((torch.ones(n, dtype=torch.int64) << torch.randint(8, 61, (n,), generator=g))
+                      + torch.randint(0, 200, (n,), generator=g)).view(torch.float64),
     }
     for name, keys in cases.items():
         ok &= check(name, keys, reps=5)

@@ -10,6 +10,7 @@ C-ABI of libmi355mc.so (montecarlo_amd._native via the host classes):
      plus bit-exact agreement with the C oracle on larger runs.
 """
 import io
+from math import ceil
 
 import numpy as np
 import pytest
@@ -369,6 +370,95 @@ def test_gc_columns_and_native_write2(big_model):
     assert buf.getvalue().split("\n")[0] == "changed\t1.00000000\t2\t3\t4\t 5.00"
 
 
+def test_order_keys_is_pythons_stable_sort():
+    """mc_order_keys == sorted(range(t), key=x.__getitem__) (lib4mc/MonteCarloParent.py:68): ties keep their
+    input order, -0.0 ties with 0.0, unparseable scores (1022.0) and inf sort where Python puts them."""
+    from montecarlo_amd.engine import device_order
+    rng = np.random.default_rng(21)
+    cases = {
+        "ties": np.round(rng.random(300000) * 40, 1),
+        "distinct": rng.random(200001) * 90,
+        "unparseable": np.where(rng.random(100000) < 0.3, 1022.0, rng.random(100000) * 60),
+        "zeros": np.where(rng.random(5000) < 0.5, -0.0, 0.0) * np.where(rng.random(5000) < 0.2, 0.0, 1.0),
+        "signed": np.concatenate([rng.standard_normal(70000) * 30, [np.inf, -np.inf, 0.0, -0.0, np.inf, 1022.0]]),
+        "one": np.array([3.5]),
+        "equal": np.full(70000, 17.25),
+    }
+    for name, x in cases.items():
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        srt, order = device_order(torch.from_numpy(x).cuda())
+        order = order.cpu().numpy().view(np.uint32)
+        want = np.argsort(x, kind="stable")                  # (numpy compares -0.0 == 0.0 as Python does)
+        assert np.array_equal(order, want.astype(np.uint32)), name
+        assert np.array_equal(srt.cpu().numpy().view(np.uint64), x[want].view(np.uint64)), name
+    srt, order = device_order(torch.empty(0, dtype=torch.float64, device="cuda"))
+    assert srt.numel() == 0 and order.numel() == 0
+
+
+def test_guess_numbers_equal_reference_loop():
+    """mc_guess_numbers == the reference's running expression rank = ceil(max(estimate, prev + add))
+    (lib4mc/MonteCarloLib.py:47-55) on ascending estimates, across chunk borders, with estimates that do not
+    fit int64 (the kernel reports where they start) and with the sharded form (cnt == NULL)."""
+    from math import ceil
+    from montecarlo_amd.engine import device_guess_numbers
+    rng = np.random.default_rng(3)
+    for t, scale in ((3000, 1e3), (300000, 1e9), (50000, 2.0 ** 61.9), (3000, 2.0 ** 70), (2049, 5.0), (1, 9.0)):
+        est = np.sort(rng.random(t)) * scale
+        est[:5] = [1.0, 1.0, 1.0, 2.0, 2.5][:min(5, t)]
+        cnt = (rng.random(t) > 0.05).astype(np.int64)
+        pos = np.where(cnt > 0, est, 0.0)
+        for add1 in (True, False):
+            want, prev = [], 0
+            for e, k in zip(pos.tolist(), cnt.tolist()):
+                prev = ceil(max(e if k > 0 else 1, prev + (1 if add1 else 0)))
+                want.append(prev)
+            for with_cnt in (True, False):
+                ranks, exact, _ = device_guess_numbers(torch.from_numpy(pos).cuda(),
+                                                       torch.from_numpy(cnt).cuda() if with_cnt else None, add1)
+                exact = int(exact.item())
+                fits = next((i for i, e in enumerate(pos.tolist()) if ceil(e) >= 2 ** 62), t)
+                assert exact == fits, (t, scale, add1)
+                got = ranks.cpu().numpy()
+                assert got[:exact].tolist() == want[:exact], (t, scale, add1, with_cnt)
+                # beyond the exact prefix the array carries the estimates (fp64 bits) for the caller's integers
+                assert np.array_equal(got[exact:].view(np.float64), np.where(cnt > 0, pos, 1.0)[exact:])
+    ranks, exact, _ = device_guess_numbers(torch.empty(0, dtype=torch.float64, device="cuda"), None, True)
+    assert int(exact.item()) == 0
+
+
+def test_driver_flow_on_columns_equals_tuple_flow(big_model):
+    """parse_file -> ml2p_iter2gc -> write2 as the drivers chain them (backwords_simulator.py:90-94) never builds
+    a tuple here (montecarlo_amd.columns); the same flow fed with plain lists of tuples -- which takes the
+    reference's per-row route through the same entry points -- must write the same bytes, also when guess
+    numbers leave int64 (synthetic sample keys up to 120 bits)."""
+    m, _ = big_model
+    m.seed(9)
+    g = torch.Generator().manual_seed(4)
+    few = MonteCarloLib((torch.rand(5000, generator=g, dtype=torch.float64) * 120).cuda())   # positions reach 2^107
+    many = MonteCarloLib(m.sample(300000))
+    test = synth.zipf_corpus(40000, oov_frac=0.02, stream=11) + ["zq" * 40, "p\u00e4ss", "", "\U0001f600x"]
+    for mc, add1 in ((many, True), (many, False), (few, True)):
+        scored = m.parse_file(synth.as_file(test))
+        assert type(scored).__name__ == "ScoredList" and scored.pristine
+        gcl = mc.ml2p_iter2gc(scored, add1=add1)
+        assert gcl._rows is None and scored._rows is None            # nobody looked: still columns
+        a = io.StringIO()
+        mc.write2(a)
+        rows = list(m.parse_file(synth.as_file(test)))
+        gc2 = mc.ml2p_iter2gc(rows, add1=add1)
+        assert type(gc2[0]) is tuple
+        prev = 0
+        for (_, x, _, rank, _, _) in gc2:
+            est = mc.ml2p2rank(x) if rank != prev + (1 if add1 else 0) else None
+            assert est is None or rank == ceil(max(est, prev + (1 if add1 else 0)))
+            prev = rank
+        b = io.StringIO()
+        mc.write2(b)
+        want = "".join(f"{p}\t{x:.8f}\t{c}\t{r}\t{k}\t{q:5.2f}\n" for p, x, c, r, k, q in gc2)
+        assert a.getvalue() == b.getvalue() == want
+    assert max(r[3] for r in gc2) > 2 ** 63                           # the Python-int suffix was exercised
+
+
 def test_scoring_matches_c_oracle(big_model):
     m, cm = big_model
     test = list(dict.fromkeys(synth.zipf_corpus(30000, oov_frac=0.02, stream=1))) + ["", "a" * 300]
@@ -512,12 +602,23 @@ def test_rank_key_distributions():
         "all bit patterns": torch.randint(0, 0x7FEFFFFFFFFFFFFF, (n,), generator=g, dtype=torch.int64)
         .view(torch.float64),
         "runs": torch.repeat_interleave(torch.rand(n // 1000 + 1, generator=g, dtype=torch.float64) * 90, 1000)[:n],
+        # dense groups far apart, at three scales at once: no single bucket width separates their keys
+        "nested clusters": ((torch.randint(0, 5, (n,), generator=g) << 50) + (torch.randint(0, 7, (n,), generator=g) << 25)
+                            + torch.randint(0, 1 << 12, (n,), generator=g) + (1 << 60)).view(torch.float64),
+        # the words mc_order_keys sorts: (rank of a score with many ties) << 32 | index
+        "order words": ((torch.randint(0, 300, (n,), generator=g) ** 2 << 32) + torch.arange(n) + (1 << 52))
+        .view(torch.float64),
+        # keys whose gaps grow geometrically
+        "geometric": ((torch.ones(n, dtype=torch.int64) << torch.randint(8, 61, (n,), generator=g))
+                      + torch.randint(0, 200, (n,), generator=g)).view(torch.float64),
     }
     for name, keys in cases.items():
         keys = keys.contiguous().to(dev)
         rk = DeviceRank(keys)
         srt, _ = torch.sort(keys)
         assert torch.equal(rk.keys_sorted.view(torch.int64), srt.view(torch.int64)), name
+        if name in ("nested clusters", "order words", "geometric"):
+            continue                                         # (bit patterns, not scores: no weights to sum)
         if name != "all bit patterns":                       # (there the weights overflow: 2 ** 1e308)
             ref = torch.cumsum(torch.exp2(srt - np.log2(n)), 0)
             assert float(((rk.positions - ref).abs() / ref).max()) < REL, name
@@ -610,3 +711,53 @@ def golden_path(name):
     import os
     from conftest import GOLDEN
     return os.path.join(GOLDEN, name)
+
+
+def test_rank_build_failure_path_is_loud_and_stays_inside_its_buffers():
+    """The device-side failure path of mc_rank_build, on demand (mc_rank_debug_fail: the sort's tables
+    "overflow" at the first plan): nothing is written outside keys_sorted / positions / workspace (canaries either
+    side of each), keys_in is untouched, positions are NaN, mc_rank_check reports it, DeviceRank.check and the
+    guess-number entry points raise -- and the same buffers give the right result once the knob is off."""
+    import ctypes as C
+    from montecarlo_amd import _native as nv
+    dev = torch.device("cuda")
+    n, pad = 300_000, 4096
+    g = torch.Generator(device="cpu").manual_seed(5)
+    keys = (torch.rand(n, generator=g, dtype=torch.float64) * 50 + 3).to(dev)
+    keys_before = keys.clone()
+    need = nv.lib.mc_rank_workspace_bytes(n)
+    canary = 0x5A
+    srt_buf = torch.full((n + 2 * pad,), -7.0, dtype=torch.float64, device=dev)
+    pos_buf = torch.full((n + 2 * pad,), -9.0, dtype=torch.float64, device=dev)
+    ws_buf = torch.full((need + 2 * pad * 8,), canary, dtype=torch.uint8, device=dev)
+    srt, pos, ws = srt_buf[pad:pad + n], pos_buf[pad:pad + n], ws_buf[pad * 8:pad * 8 + need]
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def build():
+        nv.check(nv.lib.mc_rank_build(C.c_void_p(keys.data_ptr()), n, n, C.c_void_p(srt.data_ptr()),
+                                      C.c_void_p(pos.data_ptr()), C.c_void_p(ws.data_ptr()), need, stream))
+
+    def canaries_intact():
+        return (bool((srt_buf[:pad] == -7.0).all()) and bool((srt_buf[pad + n:] == -7.0).all())
+                and bool((pos_buf[:pad] == -9.0).all()) and bool((pos_buf[pad + n:] == -9.0).all())
+                and bool((ws_buf[:pad * 8] == canary).all()) and bool((ws_buf[pad * 8 + need:] == canary).all()))
+
+    nv.lib.mc_rank_debug_fail(1)
+    try:
+        build()
+        info = (C.c_uint64 * 8)()
+        rc = nv.lib.mc_rank_check(C.c_void_p(ws.data_ptr()), n, stream, info)
+        assert rc == -6 and info[0] != 0 and b"failed on the device" in nv.lib.mc_last_error()
+        assert bool(torch.isnan(pos).all())
+        assert canaries_intact() and torch.equal(keys, keys_before)
+        rk = DeviceRank(keys)                                      # the host classes surface it
+        with pytest.raises(nv.NativeError, match="failed on the device"):
+            rk.check()
+        with pytest.raises(RuntimeError, match="NaN"):
+            MonteCarloLib(keys).ml2p2rank(20.0)
+    finally:
+        nv.lib.mc_rank_debug_fail(0)
+    build()
+    assert nv.lib.mc_rank_check(C.c_void_p(ws.data_ptr()), n, stream, None) == 0
+    assert torch.equal(srt.view(torch.int64), torch.sort(keys)[0].view(torch.int64))
+    assert bool(torch.isfinite(pos).all()) and canaries_intact()

@@ -435,23 +435,62 @@ def test_native_write2_formatting_equals_fstrings():
         assert _format_native(gc[:600] + [bad]) is None
 
 
-def test_monotone_ranks_equal_reference_loop():
-    """_monotone_ranks (vectorised) == the reference's running expression (lib4mc/MonteCarloLib.py:47-55),
-    including estimates beyond 2^52 where it falls back to that expression itself."""
-    from math import ceil
-    from montecarlo_amd.lib4mc.MonteCarloLib import _monotone_ranks
-    rng = np.random.default_rng(3)
-    for scale in (1e3, 1e9, 2.0 ** 70):
-        est = np.sort(rng.random(3000)) * scale
-        est[:5] = [1.0, 1.0, 1.0, 2.0, 2.5]
-        cnt = (rng.random(3000) > 0.05).astype(np.int64)
-        est = np.where(cnt > 0, est, 1.0)
-        for add1 in (True, False):
-            want, prev = [], 0
-            for e in est:
-                prev = ceil(max(e, prev + (1 if add1 else 0)))
-                want.append(prev)
-            assert _monotone_ranks(est, cnt, add1) == want
+def test_format_gc_cps_equals_fstrings():
+    """mc_format_gc_cps (passwords as the ingest's code points + an order) writes what the reference's f-string
+    writes (lib4mc/MonteCarloLib.py:65-66), multi-byte characters included; a lone surrogate is refused."""
+    from montecarlo_amd.ingest import UniqueLines
+    rng = np.random.default_rng(11)
+    alphabet = "abcXYZ019!\u00e9\u4e2d\U0001f600\t "
+    pw = ["".join(alphabet[i] for i in rng.integers(0, len(alphabet), rng.integers(0, 12))) + f"#{k}"
+          for k in range(700)]
+    lines = UniqueLines("\n".join(pw) + "\n")
+    assert lines.strings() == pw
+    order = rng.permutation(len(pw)).astype(np.uint32)
+    n = len(pw)
+    mlp = np.sort(rng.random(n) * 200)
+    apps = rng.integers(1, 50, n).astype(np.int64)
+    rank = np.cumsum(rng.integers(1, 2 ** 40, n)).astype(np.int64)
+    crk = np.cumsum(apps)
+    ratio = crk / float(crk[-1]) * 100
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    out = np.empty(4 * len(lines.cps) + 120 * n, dtype=np.uint8)
+    size = nv.lib.mc_format_gc_cps(vp(lines.cps), vp(lines.off), vp(order), n, vp(mlp), vp(apps), vp(rank), vp(crk),
+                                   vp(ratio), vp(out), out.size)
+    want = "".join(f"{pw[o]}\t{m:.8f}\t{a}\t{r}\t{c}\t{q:5.2f}\n"
+                   for o, m, a, r, c, q in zip(order.tolist(), mlp.tolist(), apps.tolist(), rank.tolist(),
+                                               crk.tolist(), ratio.tolist()))
+    assert size == len(want.encode("utf-8")) and bytes(out[:size]).decode("utf-8") == want
+    assert nv.lib.mc_format_gc_cps(vp(lines.cps), vp(lines.off), vp(order), n, vp(mlp), vp(apps), vp(rank), vp(crk),
+                                   vp(ratio), vp(out), 100) < 0                     # dst too small
+    bad = UniqueLines("ab\n\ud800x\n")
+    two = np.arange(2, dtype=np.uint32)
+    assert nv.lib.mc_format_gc_cps(vp(bad.cps), vp(bad.off), vp(two), 2, vp(mlp), vp(apps), vp(rank), vp(crk),
+                                   vp(ratio), vp(out), out.size) < 0
+
+
+def test_column_lists_behave_as_the_lists_they_replace():
+    """ScoredList / GcList (montecarlo_amd.columns) against plain lists of tuples: length, indexing, slicing,
+    iteration, equality, and that a change through the list interface turns `pristine` off."""
+    from montecarlo_amd.columns import GcList, ScoredList
+    from montecarlo_amd.ingest import UniqueLines
+    pw = [f"pw{k}" for k in range(50)]
+    lines = UniqueLines("\n".join(pw + pw[:7]) + "\n")
+    ml2p = np.linspace(1, 20, 50)
+    order = np.arange(50, dtype=np.uint32)[::-1].copy()
+    sc = ScoredList(order, lines.count[order].astype(np.int64), ml2p, lines=lines)
+    want = [(pw[o], int(lines.count[o]), float(m)) for o, m in zip(order.tolist(), ml2p.tolist())]
+    assert len(sc) == 50 and sc.pristine
+    assert sc == want and want == list(sc) and sc[3] == want[3] and sc[-2:] == want[-2:]
+    assert [type(v) for v in sc[0]] == [str, int, float]
+    ranks = np.arange(1, 51, dtype=np.int64) * 3
+    crk = np.cumsum(sc.count)
+    gcl = GcList(sc, ranks, crk, crk / float(crk[-1]) * 100)
+    rows = [(p, m, a, r, c, c / int(crk[-1]) * 100) for (p, a, m), r, c in zip(want, ranks.tolist(), crk.tolist())]
+    assert gcl == rows and gcl.pristine and len(gcl) == 50
+    gcl[0] = ("zz", 1.0, 1, 1, 1, 1.0)
+    assert not gcl.pristine and gcl[0][0] == "zz" and gcl[1:] == rows[1:]
+    sc.sort(key=lambda r: r[0])
+    assert not sc.pristine and sc == sorted(want, key=lambda r: r[0])
 
 
 def test_c_abi_rejects_bad_arguments_before_touching_the_device():
@@ -478,6 +517,13 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_device():
     rejected(lib.mc_rank_build(a, 2 ** 32, 2 ** 32, b, c, big, 1 << 62, None), "2\\^32")
     rejected(lib.mc_rank_build(a, 10, 10, b, c, big, need - 1, None), "workspace")
     assert lib.mc_rank_query(None, None, 0, None, 0, None, None, None) == 0
+    assert lib.mc_order_keys(None, 0, None, None, None, 0, None) == 0
+    oneed = lib.mc_order_workspace_bytes(10)
+    rejected(lib.mc_order_keys(a, 10, a, c, big, oneed, None), "mc_order_keys")       # sorted over the input
+    rejected(lib.mc_order_keys(a, 10, b, None, big, oneed, None), "mc_order_keys")
+    rejected(lib.mc_order_keys(a, 2 ** 32, b, c, big, 1 << 62, None), "2\\^32")
+    rejected(lib.mc_order_keys(a, 10, b, c, big, oneed - 1, None), "workspace")
+    rejected(lib.mc_guess_numbers(a, None, 10, 1, b, None, big, 1 << 20, None), "mc_guess_numbers")
     rejected(lib.mc_rank_query(a, b, 10, None, 5, c, None, None), "mc_rank_query")
     rejected(lib.mc_rank_query(None, b, 10, a, 5, c, None, None), "mc_rank_query")
     rejected(lib.mc_sample(None, 0, 10, 1, 100, a, None, None, None, 0, None), "mc_sample")

@@ -56,6 +56,14 @@ B_DRAW, B_INDIRECT, B_PROBE, B_SAMPLE = 16, 16, 8, 8
 B_RANK = 40
 
 
+class _NoEvent:
+    def record(self, *a):
+        pass
+
+    def elapsed_time(self, other):
+        return 1e-9
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,9 +73,11 @@ def main():
     ap.add_argument("--tests", type=int, default=1_000_000)
     ap.add_argument("--train-lines", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap-score", action="store_true",
-                    help="score the test set on a second stream beside the rank build")
-    ap.add_argument("--serial", action="store_true", help=argparse.SUPPRESS)        # (the default now)
+    ap.add_argument("--serial", action="store_true",
+                    help="everything on one stream (the default scores and orders the test set, which do not depend "
+                         "on the samples, on a second stream beside sampling and the rank build)")
+    ap.add_argument("--overlap-score", action="store_true", help=argparse.SUPPRESS)  # (the default now)
+    ap.add_argument("--bare", action="store_true", help=argparse.SUPPRESS)   # experiment: no stage events
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="rehearsal of the multi-rank control flow on a 1-GPU box: every rank uses cuda:0 and the "
                          "collective runs over gloo (the printed numbers mean nothing)")
@@ -129,47 +139,53 @@ def main():
     seed = 20250304
 
     ev = {k: [] for k in ("sample", "rank", "score", "order", "query", "guess_numbers", "d2h")}
-    side = torch.cuda.Stream(device=dev) if args.overlap_score else None
+    side = torch.cuda.Stream(device=dev) if not args.serial else None
     main_stream = torch.cuda.current_stream(dev)
 
     rk_last = [None]
 
     def step(it: int, timed: bool):
-        """sample -> rank build -> score -> queries on the main stream (--overlap-score: the test set is
-        scored on a second stream beside the rank build; it does not depend on the samples)."""
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(12)]
+        """sample -> rank build -> [score -> order] -> queries -> guess numbers; the bracketed part runs on a
+        second stream from the start of the step unless --serial, the copies to the host on a third."""
+        marks = [torch.cuda.Event(enable_timing=True) if not args.bare or i in (6, 8, 11) else _NoEvent()
+                 for i in range(12)]
         slot = it & 1
         first = (it * world + rank) * N                     # disjoint Philox sample ids per rank and step
         marks[0].record()
+        if side is not None:
+            # the test set's scores and their order do not depend on the samples: a second stream computes them
+            # beside sampling and the rank build (small, latency-bound launches under two chip-wide ones)
+            side.wait_event(marks[0])
+            with torch.cuda.stream(side):
+                if copied[slot] is not None:                # this set's copies of two steps ago
+                    side.wait_event(copied[slot])
+                    copied[slot] = None
+                marks[3].record()
+                dm.score_device(d_syms, d_off, T, out=t_ml2p)
+                marks[4].record()
+                device_order(t_ml2p, out_sorted=t_sorted[slot], out_order=t_order[slot], workspace=ws_order)
+                marks[6].record()
         dm.sample(N, seed, first_id=first, out=keys)
         marks[1].record()
         for i, done in enumerate(reduced):                  # the previous step's all-reduce ran beside k_sample
             if done is not None:
                 main_stream.wait_event(done)
                 reduced[i] = None
-        if side is not None:
-            # beside the rank build, not beside k_sample (both are gather-bound: measured, they only slow
-            # each other down)
-            side.wait_event(marks[1])
-            with torch.cuda.stream(side):
-                marks[3].record()
-                dm.score_device(d_syms, d_off, T, out=t_ml2p)
-                marks[4].record()
         rk = DeviceRank(keys, n_global=N * world, workspace=ws, keys_sorted=keys_sorted, positions=positions)
         rk_last[0] = rk
         marks[2].record()
         if side is None:
+            if copied[slot] is not None:
+                main_stream.wait_event(copied[slot])
+                copied[slot] = None
             marks[3].record()
             dm.score_device(d_syms, d_off, T, out=t_ml2p)
             marks[4].record()
+            device_order(t_ml2p, out_sorted=t_sorted[slot], out_order=t_order[slot], workspace=ws_order)
+            marks[6].record()
         else:
-            main_stream.wait_event(marks[4])
-        if copied[slot] is not None:                        # this set's copies of two steps ago
-            main_stream.wait_event(copied[slot])
-            copied[slot] = None
+            main_stream.wait_event(marks[6])
         marks[5].record()
-        device_order(t_ml2p, out_sorted=t_sorted[slot], out_order=t_order[slot], workspace=ws_order)
-        marks[6].record()
         rk.query(t_sorted[slot], out_pos=q_pos[slot], out_cnt=q_cnt)
         marks[7].record()
         if comm is None:
@@ -207,8 +223,8 @@ def main():
             ev["sample"].append((marks[0], marks[1]))
             ev["rank"].append((marks[1], marks[2]))
             ev["score"].append((marks[3], marks[4]))
-            ev["order"].append((marks[5], marks[6]))
-            ev["query"].append((marks[6], marks[7]))
+            ev["order"].append((marks[4], marks[6]))
+            ev["query"].append((marks[5], marks[7]))
             ev["guess_numbers"].append((marks[7] if comm is None else marks[9], marks[8]))
             ev["d2h"].append((marks[10], marks[11]))
 
@@ -226,6 +242,7 @@ def main():
     t0 = time.perf_counter()
     for s in range(args.steps):
         step(args.warmup + s, True)
+    issued = time.perf_counter() - t0                       # the host's share: launching, not waiting
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -277,7 +294,8 @@ def main():
                                "workgroup waits for another)",
                        "samples_per_gpu": N, "test_pwds": T, "contexts": int(flat.info[nv.INFO_NCTX]),
                        "entries": int(flat.info[nv.INFO_NENT]), "table_bytes": int(flat.info[nv.INFO_DEVICE_BYTES])},
-            "stage_ms": ms, "score_overlapped": side is not None,
+            "stage_ms": ms, "test_set_on_second_stream": side is not None,
+            "host_issue_ms_per_step": issued / args.steps * 1e3,
             "sampling_only_per_s": N * world / (ms["sample"] * 1e-3),
             # score + stable order + bisection + monotone guess numbers (device time of those four stages); the
             # copy of ranks/order/scores to the host (`d2h` in stage_ms) runs beside the next step

@@ -3,8 +3,8 @@
 // Sampling (replaces MonteCarlo.sample -> sample1 -> pick_expand, reference
 // lib4mc/MonteCarloParent.py:33-46, nwords_simulator.py:92-116, lib4mc/ProbLib.py:31-43):
 // one lane per sampled string, persistent: a lane that finishes a string immediately
-// claims the next sample id of its workgroup from an LDS cursor, so lanes never wait for
-// the longest string of their wave.  Every step of a lane is one draw = one 16-byte record
+// takes the next sample id of its wave's range, so lanes never wait for the longest string
+// of their wave; finished keys leave through an LDS ring, a 128-byte line at a time.  Every step of a lane is one draw = one 16-byte record
 // of the bucketed draw table (buckets that straddle a threshold: + threshold(s) + 16 B).
 // The accumulation `prob += -log2 p` is done in fp64 in draw order, so ml2p is
 // bit-identical to the reference for the same uniforms.
@@ -127,25 +127,107 @@ __device__ __forceinline__ double rec_f64(const DrawRec &q) {
 // starts with a Philox block of its own).  A draw reads ONE 16-byte record of the draw table
 // (mc_draw_rec, include/mi355mc.h); only buckets that straddle a threshold read more.  Finished
 // strings are written at the end of the iteration, so no load waits behind a store.
+constexpr unsigned int SAMPLE_WAVES = 4;  // k_sample's workgroup: 256 lanes
+constexpr unsigned int LINE_KEYS = 16;    // fp64 keys in 128 bytes
+constexpr unsigned int RING_LINES = 8;    // lines a wave keeps open
+constexpr unsigned int CHUNK_LINES = 4;   // lines (64 ids) a wave takes from its workgroup's cursor at a time
+constexpr unsigned int RING_CHUNKS = 4;   // chunk starts a wave remembers (> RING_LINES / CHUNK_LINES + 1)
+
 template <bool INJECT, bool MULTICHAR, int NC>
 __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
     // the head of the draw table (the rows with the most visits per bucket: mc_table.cpp places them
     // first) lives in LDS: a.hot_recs records, loaded once per workgroup
     extern __shared__ __align__(16) unsigned char hot_raw[];
     DrawRec *hot = (DrawRec *)hot_raw;
-    __shared__ unsigned int cursor;
     __shared__ unsigned int blk_cnt[5];
+    __shared__ unsigned int cursor;
+    // finished keys wait here until their 128-byte line is whole (see "finished strings" below)
+    __shared__ double ring_keys[SAMPLE_WAVES][RING_LINES * LINE_KEYS];
+    __shared__ unsigned int ring_bits[SAMPLE_WAVES][RING_LINES];
+    __shared__ unsigned int ring_chunk[SAMPLE_WAVES][RING_CHUNKS];
     for (uint32_t i = threadIdx.x; i < a.hot_recs; i += blockDim.x) hot[i] = ((const DrawRec *)m.draw)[i];
-    const unsigned long long per = (a.count + gridDim.x - 1) / gridDim.x;
+    // a workgroup owns `per` consecutive sample ids (a multiple of 16, so that every chunk a wave takes starts on
+    // a line of out_ml2p when that array is 128-byte aligned); its waves take them 64 at a time from a cursor
+    const unsigned long long per = ((a.count + gridDim.x - 1) / gridDim.x + (LINE_KEYS - 1)) & ~(unsigned long long)(LINE_KEYS - 1);
     const unsigned long long b0 = min(a.count, (unsigned long long)blockIdx.x * per);
     const unsigned long long b1 = min(a.count, b0 + per);
     const unsigned int nblk = (unsigned int)(b1 - b0);
+    const unsigned int wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    double *const rkeys = ring_keys[wid];
+    unsigned int *const rbits = ring_bits[wid];
+    unsigned int *const rchunk = ring_chunk[wid];
+    if (lane < RING_LINES) rbits[lane] = 0;
+    // A wave numbers the ids it takes 0, 1, 2, ... (its "slots"): slot v is id (start of chunk v / 64) + v % 64 of
+    // the workgroup's range, line v / 16 of the wave.  The chunk being handed out and the one after it are held
+    // in registers (a lane's next id is on the critical path of its next draw: no LDS round trip there);
+    // rchunk[] remembers the starts of the last RING_CHUNKS chunks for the lines still open.  All wave-uniform:
+    unsigned int w_next = 0;      // next slot to hand out
+    unsigned int w_cs = 0;        // first slot of the current chunk
+    unsigned int w_c0, w_c1;      // start ids of the current chunk and of the next one
+    unsigned int w_head = 0;      // first line of the wave that has not been written out
+    unsigned int w_done = 0;      // bit j: line w_head + j has been written out
     if (threadIdx.x == 0) cursor = 0;
     if (threadIdx.x < 5) blk_cnt[threadIdx.x] = 0;
     __syncthreads();
+    auto take_chunk = [&](unsigned int index) {  // (wave-uniform) the next 64 ids of the workgroup's range
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(&cursor, CHUNK_LINES * LINE_KEYS);
+        base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+        base = base < nblk ? base : nblk;
+        if (lane == 0) rchunk[index % RING_CHUNKS] = base;
+        return base;
+    };
+    w_c0 = take_chunk(0);
+    w_c1 = take_chunk(1);
+    auto line_base = [&](unsigned int line) {  // first id (in the workgroup's range) of an open line of this wave
+        return rchunk[(line / CHUNK_LINES) % RING_CHUNKS] + (line % CHUNK_LINES) * LINE_KEYS;
+    };
+    // hands the wave's next slots to the lanes of `want`: slot and id (wave-uniform control flow)
+    auto claim = [&](bool want, unsigned int &slot, unsigned int &id) -> bool {
+        constexpr unsigned int CHUNK = CHUNK_LINES * LINE_KEYS;
+        const unsigned long long f = __builtin_amdgcn_ballot_w64(want);
+        const unsigned int cnt = (unsigned int)__popcll(f);
+        if (cnt == 0) return false;
+        const unsigned int rank =
+            __builtin_amdgcn_mbcnt_hi((unsigned int)(f >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)f, 0u));
+        const unsigned int mine = w_next + rank, in_chunk = mine - w_cs;
+        const unsigned int at = in_chunk < CHUNK ? w_c0 + in_chunk : w_c1 + (in_chunk - CHUNK);
+        if (want) {
+            slot = mine;
+            id = at;
+        }
+        w_next += cnt;
+        // the ring holds RING_LINES lines from w_head on: a line that a slow string keeps open is written out
+        // as far as it is complete and its stragglers go to memory directly, so nobody ever waits
+        while ((w_next - 1) / LINE_KEYS >= w_head + RING_LINES) {
+            const unsigned int e = w_head % RING_LINES;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const unsigned int bits = rbits[e];
+            if (lane < LINE_KEYS && ((bits >> lane) & 1u))
+                a.out_ml2p[b0 + line_base(w_head) + lane] = rkeys[e * LINE_KEYS + lane];
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) rbits[e] = 0;
+            ++w_head;
+            w_done >>= 1;
+            while (w_done & 1u) {
+                w_done >>= 1;
+                ++w_head;
+            }
+        }
+        if (w_next >= w_cs + CHUNK) {
+            // (the table entry the new chunk takes belonged to the chunk RING_CHUNKS before it, whose lines are
+            // all below w_head: every slot handed out lies within RING_LINES lines of w_head)
+            w_cs += CHUNK;
+            w_c0 = w_c1;
+            w_c1 = take_chunk(w_cs / CHUNK + 1);
+        }
+        return want && at < nblk;
+    };
 
     unsigned int c_draws = 0, c_probes = 0, c_restart = 0, c_fail = 0, c_indirect = 0;
-    unsigned int local[NC];
+    unsigned int local[NC], slot[NC];
     uint32_t *sym_row[NC];  // where this chain's string goes (null: strings not wanted)
     uint32_t goff[NC], gbits[NC], plen[NC], nsym[NC], draw[NC];
     double acc[NC];
@@ -153,8 +235,8 @@ __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
     bool any = false;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        local[c] = atomicAdd(&cursor, 1u);
-        live[c] = local[c] < nblk;
+        local[c] = slot[c] = 0;
+        live[c] = claim(true, slot[c], local[c]);
         any |= live[c];
         sym_row[c] = a.out_syms ? a.out_syms + (b0 + local[c]) * a.sym_stride : nullptr;
         goff[c] = m.start_draw;
@@ -169,7 +251,7 @@ __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
     const double *__restrict__ rcum = m.rcum;
     const double nan = __longlong_as_double(0x7FF8000000000000ll);
 
-    while (any) {
+    while (__builtin_amdgcn_ballot_w64(any) != 0) {  // (the whole wave stays: its lanes write lines out together)
         // ---- two uniforms per chain (draw[c] is even here) ---------------------------------
         unsigned long long m53[NC][2];
         double rr[NC][2];
@@ -293,16 +375,55 @@ __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
             }
         }
         // ---- finished strings: write, claim the next id ------------------------------------------
+        // A key does not go to memory by itself (an 8-byte store into a line whose other keys arrive hundreds of
+        // cycles later was measured as 26 bytes written to HBM per key: the gathers push the half-filled line
+        // out of L2 first).  It waits in the wave's ring until the 16 keys of its line are there, and 16 lanes
+        // store the line at once.
         any = false;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
+            bool whole = false;
+            unsigned int line = 0;
             if (fresh[c]) {
                 const unsigned long long i = b0 + local[c];
-                a.out_ml2p[i] = res_ml2p[c];
+                line = slot[c] / LINE_KEYS;
+                if (line < w_head) {
+                    a.out_ml2p[i] = res_ml2p[c];  // (its line was written out without it: a straggler)
+                } else {
+                    const unsigned int e = line % RING_LINES, k = slot[c] % LINE_KEYS, bit = 1u << k;
+                    rkeys[e * LINE_KEYS + k] = res_ml2p[c];
+                    const unsigned int first = local[c] - k;  // (a line's ids: `first` .. nblk - 1 at most)
+                    const unsigned int full = nblk - first >= LINE_KEYS ? (1u << LINE_KEYS) - 1u : (1u << (nblk - first)) - 1u;
+                    whole = ((atomicOr(&rbits[e], bit) | bit) == full);
+                }
                 if (a.out_len) a.out_len[i] = res_len[c];
                 if (a.out_draws) a.out_draws[i] = res_draws[c];
-                local[c] = atomicAdd(&cursor, 1u);
-                live[c] = local[c] < nblk;
+            }
+            const bool got = claim(fresh[c], slot[c], local[c]);  // (before the ring's answer is waited for)
+            unsigned long long wm = __builtin_amdgcn_ballot_w64(whole);
+            if (wm) {
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                while (wm) {
+                    const int src = __builtin_ctzll(wm);
+                    wm &= wm - 1;
+                    const unsigned int ln = (unsigned int)__builtin_amdgcn_readlane((int)line, src);
+                    if (ln < w_head) continue;  // (the claim above has just written it out, whole)
+                    const unsigned int e = ln % RING_LINES, first = line_base(ln);
+                    if (lane < LINE_KEYS && first + lane < nblk)
+                        a.out_ml2p[b0 + first + lane] = rkeys[e * LINE_KEYS + lane];
+                    if (lane == 0) rbits[e] = 0;
+                    w_done |= 1u << (ln - w_head);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                while (w_done & 1u) {
+                    w_done >>= 1;
+                    ++w_head;
+                }
+            }
+            if (fresh[c]) {
+                live[c] = got;
                 if (a.out_syms) sym_row[c] = a.out_syms + (b0 + local[c]) * a.sym_stride;
             }
             any |= live[c];
@@ -997,14 +1118,15 @@ static int launch_sample(mc_model *m, bool inject, const SampleArgs &a_in, hipSt
     // Workgroups of 256 lanes; 16 per CU, of which 8 are resident at a time: a workgroup owns a
     // contiguous range of sample ids, and the second half of the grid evens out the ranges whose
     // strings came out long (measured: 16 per CU 12 % faster than 8, 32 and 64 slower again).
-    // 19 KB of LDS per workgroup hold the head of the draw table (8 x 19 KB fit a CU; it serves 55 %
-    // of the draws of the headline model; 40 KB costs more in occupancy than it saves).  One or two
+    // 15 KB of LDS per workgroup hold the head of the draw table (with the 4 KB of the waves' key rings 8
+    // workgroups fit a CU; it serves about half of the draws of the headline model; 40 KB costs more in
+    // occupancy than it saves).  One or two
     // chains per lane perform alike once the table is placed hot-first.  All are tuning knobs
     // (results never depend on them: tests/test_gpu_parity.py).  Each workgroup's share of the
     // sample ids must fit u32.
     static const int env_nc = getenv("MC_SAMPLE_CHAINS") ? atoi(getenv("MC_SAMPLE_CHAINS")) : 1;
     static const int env_wg = getenv("MC_SAMPLE_WG_PER_CU") ? atoi(getenv("MC_SAMPLE_WG_PER_CU")) : 16;
-    static const int env_hot = getenv("MC_SAMPLE_HOT_KB") ? atoi(getenv("MC_SAMPLE_HOT_KB")) : 19;
+    static const int env_hot = getenv("MC_SAMPLE_HOT_KB") ? atoi(getenv("MC_SAMPLE_HOT_KB")) : 15;
     const int nc = inject ? 1 : env_nc;
     {
         unsigned long long recs = (unsigned long long)(env_hot < 0 ? 0 : env_hot > 150 ? 150 : env_hot) * 1024 / 16;

@@ -221,7 +221,8 @@ extern "C" int mc_order_keys(const double *x, uint64_t t, double *x_sorted, uint
     if (rc != MC_OK) return rc;
     hipLaunchKernelGGL(k_order_words, dim3(g), dim3(256), 0, s, (const u64 *)x_sorted, (const u64 *)x, (u64)t, words,
                        (const u32 *)err1, failed);
-    rc = mc_sort_keys((const uint64_t *)words, t, (uint64_t *)words_sorted, workspace, sort_bytes, &err2, 0, s);
+    rc = mc_sort_keys((const uint64_t *)words, t, (uint64_t *)words_sorted, workspace, sort_bytes, &err2,
+                      MC_SORT_FEW_REPEATS /* the words are distinct */, s);
     if (rc != MC_OK) return rc;
     hipLaunchKernelGGL(k_order_out, dim3(g), dim3(256), 0, s, (const u64 *)words_sorted, (const u64 *)x, (u64)t, order,
                        (u64 *)x_sorted, (const u32 *)err2, (const u32 *)failed);

@@ -194,7 +194,7 @@ extern "C" int mc_rank_build(const double *keys_in, uint64_t n, uint64_t n_globa
     uint32_t *err = nullptr;
     {
         int rc = mc_sort_keys((const uint64_t *)keys_in, n, (uint64_t *)keys_sorted, workspace, sort_bytes, &err,
-                              g_debug_fail.load(), s);
+                              g_debug_fail.load() ? MC_SORT_DEBUG_FAIL : 0, s);
         if (rc != MC_OK) return rc;
     }
     // positions

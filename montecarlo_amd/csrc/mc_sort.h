@@ -11,10 +11,12 @@ size_t mc_sort_workspace_bytes(uint64_t n);
 // Sorts n u64 keys (fp64 bit patterns of non-negative doubles: IEEE bit order = numeric order) from `in`
 // (left untouched) into `out`, ascending, asynchronously on `stream`.  Allocates nothing.  *err_word_out
 // receives the device address of the sort's error word: non-zero after the sort means a table overflowed
-// and `out` is not sorted (the caller poisons what it derives from it).  debug_fail != 0 forces that
-// failure path (tests).
+// and `out` is not sorted (the caller poisons what it derives from it).  flags: MC_SORT_DEBUG_FAIL forces that
+// failure path (tests); MC_SORT_FEW_REPEATS says no value is expected to repeat often (the search for heavy
+// values and the kernel that writes their runs are not launched; any input is still sorted correctly).
+enum { MC_SORT_DEBUG_FAIL = 1, MC_SORT_FEW_REPEATS = 2 };
 int mc_sort_keys(const uint64_t *in, uint64_t n, uint64_t *out, void *workspace, size_t workspace_bytes,
-                 uint32_t **err_word_out, int debug_fail, hipStream_t stream);
+                 uint32_t **err_word_out, int flags, hipStream_t stream);
 
 // Host copy of the sort's counters after `stream` has drained: {error word, heavy values, tail keys,
 // levels used, finish tiles, segments created, 0, 0}.

@@ -1226,7 +1226,8 @@ Layout layout_for(u64 n) {
 size_t mc_sort_workspace_bytes(uint64_t n) { return layout_for(n).end; }
 
 int mc_sort_keys(const uint64_t *in, uint64_t n, uint64_t *out, void *workspace, size_t workspace_bytes,
-                 uint32_t **err_word_out, int debug_fail, hipStream_t s) {
+                 uint32_t **err_word_out, int flags, hipStream_t s) {
+    const bool debug_fail = (flags & MC_SORT_DEBUG_FAIL) != 0, few_repeats = (flags & MC_SORT_FEW_REPEATS) != 0;
     const Layout L = layout_for(n);
     if (workspace_bytes < L.end) {
         mc_set_error("mc_sort_keys: workspace of %zu bytes, need %zu", workspace_bytes, L.end);
@@ -1260,7 +1261,7 @@ int mc_sort_keys(const uint64_t *in, uint64_t n, uint64_t *out, void *workspace,
 
     HIP_TRY(hipMemsetAsync(base + L.clear_from, 0, L.clear_bytes, s));
     const u32 g_region = L.regions < 2048u ? L.regions : 2048u;
-    hipLaunchKernelGGL(k_sniff, dim3(1), dim3(SNIFF_THREADS), 0, s, w);
+    if (!few_repeats) hipLaunchKernelGGL(k_sniff, dim3(1), dim3(SNIFF_THREADS), 0, s, w);
     hipLaunchKernelGGL(k_strip, dim3(g_region), dim3(WG), 0, s, w);
     hipLaunchKernelGGL(k_scatter<true>, dim3(g_region), dim3(WG), 0, s, w, 0);
     const u32 max_tiles = (u32)(n / TILE + 1);
@@ -1275,7 +1276,7 @@ int mc_sort_keys(const uint64_t *in, uint64_t n, uint64_t *out, void *workspace,
     if (debug_fail) hipLaunchKernelGGL(k_force_error, dim3(1), dim3(1), 0, s, w.ctl);
     const u32 g_ft = L.cap_ft < 1024u ? L.cap_ft : 1024u;
     hipLaunchKernelGGL(k_finish, dim3(g_ft), dim3(WG), 0, s, w);
-    hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, s, w);
+    if (!few_repeats) hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, s, w);  // (no heavy values: no runs)
     HIP_TRY(hipGetLastError());
     return MC_OK;
 }

@@ -37,13 +37,23 @@ from montecarlo_amd import _native as nv  # noqa: E402
 from montecarlo_amd import dist as mcd  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-# HBM bytes per launch from the last committed PMC passes (profiles/r01_*_pmc_hbm_traffic.json: FETCH_SIZE
-# doubled per the guide's gfx950 correction + WRITE_SIZE, separate rocprofv3 --pmc runs of this same
-# command).  They are measured by scripts/gpu_round.sh, not inside this process; null when absent.
-TRAFFIC = {}
+# HBM bytes per launch from the last committed PMC passes (profiles/hbm_traffic_latest.json: FETCH_SIZE doubled per
+# the guide's gfx950 correction + WRITE_SIZE, separate rocprofv3 --pmc runs of this same command, measured by
+# scripts/gpu_round.sh and published by scripts/publish_profile.py -- not inside this process).  The file names the
+# commit and the digest of the native sources it was measured on: when the tree this process runs from has other
+# sources, the numbers are stale and `traffic` is null.
+TRAFFIC, TRAFFIC_SOURCE = {}, "none (profiles/hbm_traffic_latest.json absent)"
 try:
-    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic_latest.json")) as _f:
-        TRAFFIC = json.load(_f)
+    with open(os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")) as _f:
+        _t = json.load(_f)
+    from montecarlo_amd.build import sources_digest  # noqa: E402
+    if _t.get("csrc_sha256") and _t["csrc_sha256"] == sources_digest():
+        TRAFFIC = _t
+        TRAFFIC_SOURCE = (f"{_t.get('source')} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this command at commit "
+                          f"{str(_t.get('commit'))[:12]}, native sources unchanged since)")
+    else:
+        TRAFFIC_SOURCE = (f"stale: {_t.get('source')} was measured at commit {str(_t.get('commit'))[:12]} on other "
+                          f"native sources than this tree's")
 except (OSError, ValueError):
     pass
 # algorithmic bytes of k_sample: one 16-B draw-table record per draw, one more 16-B
@@ -54,6 +64,27 @@ B_DRAW, B_INDIRECT, B_PROBE, B_SAMPLE = 16, 16, 8, 8
 # rank build, algorithmic minimum: every key read once and written once in order (16 B),
 # weight sums read it again (8 B), positions read it and write the running sum (16 B)
 B_RANK = 40
+
+
+def first_id(it: int, world: int, rank: int, n: int) -> int:
+    """First Philox sample id of `rank` in step `it`: step-major, rank-minor, n ids each."""
+    return (it * world + rank) * n
+
+
+def id_plan(world: int, steps: int, n: int):
+    """[(step, rank, first id, end id)] of a run, after checking that no two (step, rank) share a sample id, that a
+    step's ranks tile one contiguous block of world * n ids (what a single GPU drawing n_global = world * n samples
+    would use) and that nothing exceeds the 64-bit counter."""
+    plan = [(it, r, first_id(it, world, r, n), first_id(it, world, r, n) + n) for it in range(steps) for r in range(world)]
+    by_start = sorted(plan, key=lambda p: p[2])
+    for a, b in zip(by_start, by_start[1:]):
+        assert a[3] <= b[2], f"sample ids overlap: step {a[0]} rank {a[1]} and step {b[0]} rank {b[1]}"
+    for it in range(steps):
+        mine = [p for p in plan if p[0] == it]
+        assert mine[0][2] == it * world * n and mine[-1][3] == (it + 1) * world * n
+        assert all(x[3] == y[2] for x, y in zip(mine, mine[1:])), f"step {it}: the ranks' ranges leave a gap"
+    assert by_start[-1][3] < 1 << 64
+    return plan
 
 
 class _NoEvent:
@@ -73,10 +104,17 @@ def main():
     ap.add_argument("--tests", type=int, default=1_000_000)
     ap.add_argument("--train-lines", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--serial", action="store_true",
-                    help="everything on one stream (the default scores and orders the test set, which do not depend "
-                         "on the samples, on a second stream beside sampling and the rank build)")
-    ap.add_argument("--overlap-score", action="store_true", help=argparse.SUPPRESS)  # (the default now)
+    ap.add_argument("--second-stream", action="store_true",
+                    help="score and order the test set (they do not depend on the samples) on a second stream beside "
+                         "sampling and the rank build; measured slower than one stream (1.71 vs 1.56 ms a step: the "
+                         "sampler fills the chip, the small launches only wait longer)")
+    ap.add_argument("--serial", action="store_true", help=argparse.SUPPRESS)         # (the default)
+    ap.add_argument("--d2h", choices=("overlap", "inline"), default="overlap",
+                    help="copies of the results to the host: on a copy stream beside the next step (default; measured "
+                         "1.54 ms a step) or on the main stream inside the step (1.76 ms)")
+    ap.add_argument("--dry", action="store_true",
+                    help="no GPU: check the sample-id plan of a --gpus N run (every rank and step draws its own "
+                         "range of Philox ids, n_global = N x samples) and print it")
     ap.add_argument("--bare", action="store_true", help=argparse.SUPPRESS)   # experiment: no stage events
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="rehearsal of the multi-rank control flow on a 1-GPU box: every rank uses cuda:0 and the "
@@ -85,6 +123,12 @@ def main():
                     help="samples of the CPU baseline leg (default: the whole workload, about 10-20 s of one core)")
     args = ap.parse_args()
 
+    if args.dry:
+        plan = id_plan(args.gpus, args.warmup + args.steps, args.samples)
+        print(json.dumps({"dry": True, "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                          "samples_per_gpu_per_step": args.samples, "n_global_per_step": args.samples * args.gpus,
+                          "ranges_checked": len(plan), "first": plan[0], "last": plan[-1]}))
+        return
     if os.environ.get("BENCH_TRACE_AFTER"):                 # debugging aid: where is every thread after N seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["BENCH_TRACE_AFTER"]), exit=True)
@@ -103,6 +147,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    plan = id_plan(world, args.warmup + args.steps, args.samples)       # (host asserts: disjoint ids, n_global)
+    assert all(p[2] == first_id(p[0], world, p[1], args.samples) for p in plan if p[1] == rank)
 
     # ---------------- model + inputs (untimed) ----------------
     N, T = args.samples, args.tests
@@ -139,7 +185,7 @@ def main():
     seed = 20250304
 
     ev = {k: [] for k in ("sample", "rank", "score", "order", "query", "guess_numbers", "d2h")}
-    side = torch.cuda.Stream(device=dev) if not args.serial else None
+    side = torch.cuda.Stream(device=dev) if args.second_stream else None
     main_stream = torch.cuda.current_stream(dev)
 
     rk_last = [None]
@@ -150,7 +196,7 @@ def main():
         marks = [torch.cuda.Event(enable_timing=True) if not args.bare or i in (6, 8, 11) else _NoEvent()
                  for i in range(12)]
         slot = it & 1
-        first = (it * world + rank) * N                     # disjoint Philox sample ids per rank and step
+        first = first_id(it, world, rank, N)                # disjoint Philox sample ids per rank and step
         marks[0].record()
         if side is not None:
             # the test set's scores and their order do not depend on the samples: a second stream computes them
@@ -210,8 +256,9 @@ def main():
                 marks[8].record()
                 reduced[slot] = marks[8]
             ready = marks[8]
-        copy.wait_event(ready)
-        with torch.cuda.stream(copy):
+        lane = copy if args.d2h == "overlap" else (comm if comm is not None else main_stream)
+        lane.wait_event(ready)
+        with torch.cuda.stream(lane):
             marks[10].record()
             host[slot]["rank"].copy_(g_rank[slot], non_blocking=True)
             host[slot]["order"].copy_(t_order[slot], non_blocking=True)
@@ -307,6 +354,7 @@ def main():
             # the longest single launch; HBM traffic from profiles/*pmc_hbm_traffic.json (rocprofv3 --pmc)
             "roofline": {"bound": "hbm", "kernel": "k_sample", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC.get("k_sample"),
+                         "traffic_source": TRAFFIC_SOURCE,
                          "bytes_per_launch": bytes_per_launch, "kernel_ms": ms["sample"]},
             # the rank build as a whole (csrc/mc_sort.hip's launches + weight sums + positions, timed together)
             # against the 40 B/key a sort-and-scan cannot do without

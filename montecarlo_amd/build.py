@@ -19,6 +19,18 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
          "-Wall", "-Wno-unused-function"]
 
 
+def sources_digest() -> str:
+    """sha256 over the native sources the library is built from (names and bytes): a measurement of the kernels
+    (profiles/hbm_traffic_latest.json) records it, and bench.py quotes the measurement only while it still holds."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted([os.path.join(CSRC, s) for s in SOURCES] + HEADERS):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True

@@ -150,3 +150,21 @@ def test_nan_partial_from_one_shard_raises_on_every_rank(tmp_path):
     mp.spawn(_poison_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert "NaN" in open(tmp_path / f"verdict{r}.txt").read()
+
+
+def test_bench_dry_plan_gives_every_rank_and_step_its_own_sample_ids():
+    """bench.py --gpus N --dry: the host-side plan of a multi-GPU run (no 8-GPU box is needed to check it): every
+    (step, rank) draws its own Philox ids, a step's ranks tile n_global = N x samples ids without a gap."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry", "--steps", "5",
+                          "--warmup", "2"], capture_output=True, text=True, timeout=300, check=True).stdout
+    plan = json.loads(out.strip().splitlines()[-1])
+    assert plan["dry"] and plan["n_gpus"] == 8 and plan["ranges_checked"] == 56
+    assert plan["n_global_per_step"] == 8 * plan["samples_per_gpu_per_step"]
+    assert plan["last"] == [6, 7, 55 * 10_000_000, 56 * 10_000_000]
+    sys.path.insert(0, root)
+    import bench
+    assert [p[2:] for p in bench.id_plan(2, 2, 10)] == [(0, 10), (10, 20), (20, 30), (30, 40)]

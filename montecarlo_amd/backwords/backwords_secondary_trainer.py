@@ -23,6 +23,8 @@ def backwords_counter(nwords_list, splitter: str, start_chr: str, end_chr: str,
                       words: Dict[str, int] = None):
     from ..trained import NativeCounts, one_code_point, splitter_code_point
     sig = (splitter_code_point(splitter), one_code_point(start_chr), one_code_point(end_chr))
+    given_counts = nwords_dict if type(nwords_dict) is dict else None      # the caller's own objects: the
+    given_words = words if type(words) is dict else None                    # reference updates them in place (:44-78)
     if IMPORT_PLAIN_COUNTS and None not in sig and isinstance(nwords_dict, dict) and nwords_dict and words:
         # a model that comes as plain dicts (a pickle of an earlier run, the reference's or ours) resumes on
         # the native path when it has the shape the secondary trainer builds
@@ -41,7 +43,17 @@ def backwords_counter(nwords_list, splitter: str, start_chr: str, end_chr: str,
             text = read_lines_keep_open(nwords_list).read()
         counts = NativeCounts() if nwords_dict is None else nwords_dict
         counts.merge(text, sig[0], start4words, step4words, max_gram, threshold, sig[1], sig[2])
-        return counts, counts.words()
+        merged_words = counts.words()
+        if given_words is not None:
+            given_words.clear()
+            given_words.update(merged_words)
+        if given_counts is not None:
+            # a caller that keeps using the dicts it passed in (the reference's main pickles its own `words`
+            # argument, not the return value) sees the merge, as with the reference; this happens once per
+            # resumed pickle -- later rounds pass the NativeCounts this call returns
+            given_counts.clear()
+            given_counts.update({ctx: dict(row) for ctx, row in counts.items()})
+        return counts, (given_words if given_words is not None else merged_words)
     if isinstance(nwords_dict, NativeCounts):
         nwords_dict = {ctx: dict(row) for ctx, row in nwords_dict.items()}
     if nwords_dict is None:

@@ -303,6 +303,9 @@ def test_reference_pickle_resumes_natively(train_char):
                                         words=words)
     assert isinstance(counts1, NativeCounts)
     assert digest([[list(k), sorted(v.items())] for k, v in counts1.items()]) == fx["meta"]["counts_digest"]
+    # the reference updates the caller's dicts in place (backwords_secondary_trainer.py:44-78): so does this
+    assert words1 is words and list(words.items()) == list(counts1.words().items())
+    assert [(k, list(v.items())) for k, v in counts.items()] == [(k, list(v.items())) for k, v in counts1.items()]
     m1 = BackWordsSecondaryMonteCarlo((counts1, words1, cfg))
     check_table(fx["round1"], m1)
     # our own pickle of round 0 -> plain dicts -> native again -> same round 1

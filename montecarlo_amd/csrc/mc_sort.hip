@@ -75,6 +75,7 @@ struct Ctl {
     u32 ntile[MAX_LEVELS + 1];
     u32 nft;
     u32 segs_total;
+    u32 deep_top;  // segments handed to k_deep's workgroups by their own plans (entries of the deep arena)
 };
 
 struct Seg {
@@ -520,7 +521,7 @@ struct PlanLds {
     u32 next_bd[257];   // (suffix min-scan) first boundary bin at or after b; [256] = 256
     u32 flag[256];      // bin starts a packed finish tile
     u32 wtot[NWAVE];
-    u32 ft_base, seg_base, tile_base, ok;
+    u32 ft_base, seg_base, tile_base, ok, n_big;
 };
 
 // Decide what becomes of every bin of one segment (run by ONE workgroup per segment; `coff` = the bins'
@@ -529,14 +530,17 @@ struct PlanLds {
 // (it ends before two windows are over, so it holds < CAP keys); a bin of up to CAP keys is a tile of its own; a
 // larger bin whose keys are all equal is cut into tiles as it lies; any other larger bin is a segment of the next
 // level.  All of it in parallel over the 256 bins: a serial walk by one lane was the longest thing in the kernel.
-__device__ void plan_segment(const Ws &w, int level, u32 seg_off, u32 seg_size, u32 shift, const HistRow *row,
-                             const u32 *coff, u32 dst_id, PlanLds &pl) {
+// `deep` != nullptr (k_deep): the next level's segments go to that arena (level in `pad`), pl.seg_base / pl.n_big
+// say where; no tiles are listed and no rows cleared -- the workgroup that planned them sorts them itself.
+__device__ void plan_segment(const Ws &w, int level, u32 seg_off, u32 seg_size, u32 shift, const u32 *rcnt,
+                             const u64 *rorv, const u64 *rnorv, const u32 *coff, u32 dst_id, PlanLds &pl,
+                             Seg *deep = nullptr, u32 deep_cap = 0) {
     const int tid = threadIdx.x;
     const int next = (level + 1) & 1;
     u32 cls = 0, c = 0, csh = 0;  // 0 empty, 1 packed, 2 own tile, 3 large and all equal, 4 large
     if (tid < 256) {
-        c = row->cnt[tid];
-        const u64 o = row->orv[tid], no = row->norv[tid];
+        c = rcnt[tid];
+        const u64 o = rorv[tid], no = rnorv[tid];
         const bool known = (o | no) != 0;
         const u64 diff = o ^ ~no;
         if (c) {
@@ -606,10 +610,19 @@ __device__ void plan_segment(const Ws &w, int level, u32 seg_off, u32 seg_size, 
             ok = 0;
         }
         pl.seg_base = pl.tile_base = 0;
+        pl.n_big = tot_big;
         if (tot_big) {
             if (level + 1 >= MAX_LEVELS) {  // cannot happen: the digit moves down by >= 8 bits per level
                 atomicOr(&w.ctl->err, ERR_LEVEL);
                 ok = 0;
+            } else if (deep) {
+                pl.seg_base = atomicAdd(&w.ctl->deep_top, tot_big);
+                if ((u64)pl.seg_base + tot_big > (u64)deep_cap) {
+                    atomicOr(&w.ctl->err, ERR_SEG);
+                    ok = 0;
+                }
+                atomicMax(&w.ctl->levels_used, (u32)(level + 2));
+                atomicAdd(&w.ctl->segs_total, tot_big);
             } else {
                 pl.seg_base = atomicAdd(&w.ctl->nseg[level + 1], tot_big);
                 pl.tile_base = atomicAdd(&w.ctl->ntile[level + 1], tot_tl);
@@ -647,7 +660,14 @@ __device__ void plan_segment(const Ws &w, int level, u32 seg_off, u32 seg_size, 
         f.pad = 0;
         w.ft[pl.ft_base + tot_ft + ex_chunk + q] = f;
     }
-    if (is_big) {
+    if (is_big && deep) {
+        Seg s;
+        s.off = seg_off + coff[tid];
+        s.size = c;
+        s.shift = csh;
+        s.pad = (u32)(level + 1);
+        deep[pl.seg_base + ex_big] = s;
+    } else if (is_big) {
         Seg s;
         s.off = seg_off + coff[tid];
         s.size = c;
@@ -663,7 +683,7 @@ __device__ void plan_segment(const Ws &w, int level, u32 seg_off, u32 seg_size, 
         }
     }
     // clean histogram rows for the new segments (they are consecutive)
-    {
+    if (!deep) {
         u32 *p = (u32 *)&w.rows[next][pl.seg_base];
         const u32 words = tot_big * (u32)(sizeof(HistRow) / 4);
         for (u32 j = tid; j < words; j += WG) p[j] = 0;
@@ -717,7 +737,7 @@ __global__ void __launch_bounds__(WG) k_scatter(Ws w, int level) {
         }
         __syncthreads();
         if (blockIdx.x == 0) {
-            plan_segment(w, 0, 0u, sg.size, sg.shift, row, coff, dst_id, pl);
+            plan_segment(w, 0, 0u, sg.size, sg.shift, row->cnt, row->orv, row->norv, coff, dst_id, pl);
             if (tid == 0) atomicMax(&w.ctl->levels_used, 1u);
         }
     } else {
@@ -747,7 +767,7 @@ __global__ void __launch_bounds__(WG) k_scatter(Ws w, int level) {
                 }
                 __syncthreads();
             }
-            if (ref.k == 0) plan_segment(w, level, sg.off, sg.size, sg.shift, row, coff, dst_id, pl);
+            if (ref.k == 0) plan_segment(w, level, sg.off, sg.size, sg.shift, row->cnt, row->orv, row->norv, coff, dst_id, pl);
             base_in = sg.off;
             tile_lo = ref.k * TILE;
             tile_hi = sg.size - tile_lo < (u32)TILE ? sg.size : tile_lo + TILE;
@@ -795,6 +815,145 @@ __global__ void __launch_bounds__(WG) k_scatter(Ws w, int level) {
                 else atomicOr(&w.ctl->err, ERR_RANGE);
             }
             __syncthreads();
+        }
+    }
+}
+
+// ---- the levels below the launched ones ------------------------------------------------------------------
+// A segment that is still too large after the last launched level is finished by ONE workgroup through all its
+// remaining levels: count, plan and scatter as above, but over the segment's own tiles in turn, with the histogram
+// and the cursors in LDS and the segments it splits off on a stack of its own (depth-first; a segment's subtree
+// touches nobody else's keys).  No launch per level, nothing to wait for.  Such segments are rare and small on
+// the keys this library sorts (a few clustered value ranges); a large input keeps more launched levels instead.
+__global__ void __launch_bounds__(WG) k_deep(Ws w, int level0, Seg *arena, u32 arena_cap) {
+    __shared__ u64 stage[TILE];
+    __shared__ u32 hc[256];
+    __shared__ u64 hor[256], hnor[256];
+    __shared__ u32 lcnt[256], lstart[256], gbase[256], coff[256], csize[256], cur[256];
+    __shared__ u32 wtot[NWAVE];
+    __shared__ PlanLds pl;
+    __shared__ u32 st_lo[MAX_LEVELS + 1], st_hi[MAX_LEVELS + 1];
+    __shared__ int sp;
+    const int tid = threadIdx.x;
+    if (w.ctl->err) return;
+    const u32 ns = w.ctl->nseg[level0] < w.cap_seg ? w.ctl->nseg[level0] : w.cap_seg;
+    for (u32 si = blockIdx.x; si < ns; si += gridDim.x) {
+        Seg sg = w.segs[level0 & 1][si];
+        sg.pad = (u32)level0;
+        if (tid == 0) sp = 0;
+        for (;;) {
+            // ---- one segment: sg (its level in sg.pad) ----
+            const int level = (int)sg.pad;
+            const u64 *src = (level & 1) ? (const u64 *)w.C : (const u64 *)w.B;
+            u64 *dst = (level & 1) ? w.B : w.C;
+            const u32 dst_id = (level & 1) ? (u32)SRC_B : (u32)SRC_C;
+            __syncthreads();
+            if (tid < 256) {
+                hc[tid] = 0;
+                hor[tid] = 0;
+                hnor[tid] = 0;
+            }
+            __syncthreads();
+            for (u32 k0 = 0; k0 < sg.size; k0 += TILE) {
+                const u32 m = sg.size - k0 < (u32)TILE ? sg.size - k0 : (u32)TILE;
+                const u64 *p = src + sg.off + k0;
+#pragma unroll
+                for (int q = 0; q < ITEMS; ++q) {
+                    const u32 j = q * WG + tid;
+                    if (j < m) {
+                        const u64 key = p[j];
+                        const u32 d = (u32)(key >> sg.shift) & 255u;
+                        atomicAdd(&hc[d], 1u);
+                        atomicOr(&hor[d], key);
+                        atomicOr(&hnor[d], ~key);
+                    }
+                }
+            }
+            __syncthreads();
+            {
+                u32 tot;
+                const u32 v = tid < 256 ? hc[tid] : 0u;
+                const u32 ex = wg_excl_scan(v, wtot, tot);
+                if (tid < 256) {
+                    coff[tid] = ex;
+                    csize[tid] = v;
+                    cur[tid] = 0;
+                }
+                __syncthreads();
+                if (tot != sg.size) {  // (keys changed under the sort: poison, write nothing)
+                    if (tid == 0) atomicOr(&w.ctl->err, ERR_RANGE);
+                    return;
+                }
+            }
+            plan_segment(w, level, sg.off, sg.size, sg.shift, hc, hor, hnor, coff, dst_id, pl, arena, arena_cap);
+            __syncthreads();
+            if (!pl.ok) return;
+            for (u32 k0 = 0; k0 < sg.size; k0 += TILE) {
+                const u32 m = sg.size - k0 < (u32)TILE ? sg.size - k0 : (u32)TILE;
+                if (tid < 256) lcnt[tid] = 0;
+                __syncthreads();
+                u64 k[ITEMS];
+                u32 rk[ITEMS];
+                const u64 *p = src + sg.off + k0;
+#pragma unroll
+                for (int q = 0; q < ITEMS; ++q) {
+                    const u32 j = q * WG + tid;
+                    k[q] = j < m ? p[j] : 0ull;
+                }
+#pragma unroll
+                for (int q = 0; q < ITEMS; ++q) {
+                    const u32 j = q * WG + tid;
+                    rk[q] = j < m ? atomicAdd(&lcnt[(u32)(k[q] >> sg.shift) & 255u], 1u) : 0u;
+                }
+                __syncthreads();
+                u32 tot;
+                const u32 v = tid < 256 ? lcnt[tid] : 0u;
+                const u32 ex = wg_excl_scan(v, wtot, tot);
+                if (tid < 256) {
+                    lstart[tid] = ex;
+                    gbase[tid] = cur[tid];
+                    cur[tid] += v;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < ITEMS; ++q) {
+                    const u32 j = q * WG + tid;
+                    if (j < m) stage[lstart[(u32)(k[q] >> sg.shift) & 255u] + rk[q]] = k[q];
+                }
+                __syncthreads();
+                for (u32 j = tid; j < m; j += WG) {
+                    const u64 key = stage[j];
+                    const u32 d = (u32)(key >> sg.shift) & 255u;
+                    const u32 in_bin = gbase[d] + (j - lstart[d]);
+                    if (in_bin < csize[d]) dst[(u64)sg.off + coff[d] + in_bin] = key;
+                    else atomicOr(&w.ctl->err, ERR_RANGE);
+                }
+                __syncthreads();
+            }
+            // ---- what it split off goes on the stack; take the next segment from there ----
+            if (tid == 0) {
+                if (pl.n_big) {
+                    if (sp <= MAX_LEVELS) {
+                        st_lo[sp] = pl.seg_base;
+                        st_hi[sp] = pl.seg_base + pl.n_big;
+                        ++sp;
+                    } else {
+                        atomicOr(&w.ctl->err, ERR_LEVEL);  // (deeper than 64-bit keys can nest: impossible)
+                    }
+                }
+                while (sp > 0 && st_lo[sp - 1] == st_hi[sp - 1]) --sp;
+            }
+            __syncthreads();
+            if (sp == 0) break;
+            {  // (written by this workgroup's own lanes a moment ago, beside other workgroups' entries: read past L1)
+                const Seg *e = arena + st_lo[sp - 1];
+                sg.off = __hip_atomic_load(&e->off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sg.size = __hip_atomic_load(&e->size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sg.shift = __hip_atomic_load(&e->shift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sg.pad = __hip_atomic_load(&e->pad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            if (tid == 0) ++st_lo[sp - 1];
         }
     }
 }
@@ -1265,13 +1424,26 @@ int mc_sort_keys(const uint64_t *in, uint64_t n, uint64_t *out, void *workspace,
     hipLaunchKernelGGL(k_strip, dim3(g_region), dim3(WG), 0, s, w);
     hipLaunchKernelGGL(k_scatter<true>, dim3(g_region), dim3(WG), 0, s, w, 0);
     const u32 max_tiles = (u32)(n / TILE + 1);
-    for (int level = 1; level < MAX_LEVELS; ++level) {
+    // Levels 1 .. deep_from - 1 are launches over all tiles of all segments; what is still too large then is
+    // finished by single workgroups (k_deep).  Two launched levels resolve 24 bits of spread on top of the finish
+    // tiles' 12: beyond them segments are few on these keys, and every further launched level costs two dependent
+    // launches whether it finds work or not.  A large input keeps them all: there a deep segment is too much for
+    // one workgroup.
+    const int deep_from = n <= (1ull << 25) ? 3 : MAX_LEVELS;
+    for (int level = 1; level < deep_from; ++level) {
         // deeper levels hold less and less (a bin must exceed CAP keys AND not be one repeated value to get there)
         const u32 want = level == 1 ? 2048u : level == 2 ? 1024u : 256u;
         const u32 g = max_tiles < want ? max_tiles : want;
         if (n <= (u64)CAP) break;  // one finish tile, planned by the root
         hipLaunchKernelGGL(k_count, dim3(g), dim3(WG), 0, s, w, level);
         hipLaunchKernelGGL(k_scatter<false>, dim3(g), dim3(WG), 0, s, w, level);
+    }
+    if (deep_from < MAX_LEVELS && n > (u64)CAP) {
+        // the rows of the last launched level are dead by now: their memory is the arena of k_deep's segments
+        Seg *arena = (Seg *)w.rows[(deep_from - 1) & 1];
+        const u32 arena_cap = (u32)((size_t)L.cap_seg * sizeof(HistRow) / sizeof(Seg));
+        const u32 g = L.cap_seg < 512u ? L.cap_seg : 512u;
+        hipLaunchKernelGGL(k_deep, dim3(g), dim3(WG), 0, s, w, deep_from, arena, arena_cap);
     }
     if (debug_fail) hipLaunchKernelGGL(k_force_error, dim3(1), dim3(1), 0, s, w.ctl);
     const u32 g_ft = L.cap_ft < 1024u ? L.cap_ft : 1024u;

@@ -415,6 +415,24 @@ int mc_rank_build_noalloc(const double *keys_in, uint64_t n, uint64_t n_global, 
 int mc_rank_query(const double *keys_sorted, const double *positions, uint64_t n, const double *x, uint64_t t,
                   double *out_pos, uint64_t *out_cnt, void *stream);
 
+/* ---- sharded estimation: the one collective of the path -------------------------------------------*/
+/* SURVEY.md §8(b)/(e).  The reference is single-process and has no counterpart; what is summed is the
+ * `positions[idx - 1]` of ml2p2rank (lib4mc/MonteCarloLib.py:31-32) when every rank holds a shard of the
+ * samples and has built its rank arrays with the GLOBAL n (mc_rank_build's n_global).  For callers
+ * without torch.distributed: RCCL over xGMI, bound at run time (the library loads without it).
+ *   mc_comm_unique_id   rank 0 creates the id and hands its MC_COMM_ID_BYTES bytes to the other ranks by any
+ *                       means it has (a file, MPI, a socket)
+ *   mc_comm_init        every rank, with its GPU current; blocks until all `world` ranks have called
+ *   mc_allreduce_rank   in place on device vectors: pos[t] summed over the ranks, and cnt[t] too unless NULL
+ *                       (every weight is positive, so "some rank counted a sample" is "the summed position
+ *                       is > 0": mc_guess_numbers takes cnt == NULL); asynchronous on `stream`             */
+typedef struct mc_comm mc_comm;
+#define MC_COMM_ID_BYTES 128
+int mc_comm_unique_id(unsigned char *id);
+int mc_comm_init(const unsigned char *id, int rank, int world, mc_comm **out);
+int mc_allreduce_rank(mc_comm *c, double *pos, uint64_t *cnt, uint64_t t, void *stream);
+void mc_comm_destroy(mc_comm *c);
+
 /* ---- the test set's side of guess-number estimation ----------------------------------------------*/
 /* Stable ascending order of t test passwords by -log2 p: what `sorted(..., key=lambda x: x[2])` at the end of
  * MonteCarlo.parse_file (lib4mc/MonteCarloParent.py:68) and `need_resort` of ml2p_iter2gc

@@ -95,6 +95,53 @@ def combine_positions(pos: torch.Tensor, group=None) -> torch.Tensor:
     return pos
 
 
+class NativeComm:
+    """The same sum through the C ABI (mc_comm_init / mc_allreduce_rank: RCCL without torch.distributed), for
+    callers that bind the library from another host language.  ``unique_id()`` on rank 0, its 128 bytes carried
+    to the other ranks by whatever the caller has, then every rank constructs with its GPU current."""
+
+    COMM_ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+
+        from . import _native as nv
+        buf = (C.c_ubyte * NativeComm.COMM_ID_BYTES)()
+        nv.check(nv.lib.mc_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, unique_id: bytes, rank: int, world: int):
+        import ctypes as C
+
+        from . import _native as nv
+        if len(unique_id) != self.COMM_ID_BYTES:
+            raise ValueError(f"the communicator id has {self.COMM_ID_BYTES} bytes, got {len(unique_id)}")
+        self._nv, self._h = nv, C.c_void_p()
+        nv.check(nv.lib.mc_comm_init(unique_id, rank, world, C.byref(self._h)))
+        self.rank, self.world = rank, world
+
+    def combine(self, pos: torch.Tensor, cnt: torch.Tensor = None) -> torch.Tensor:
+        import ctypes as C
+        assert pos.is_cuda and pos.dtype == torch.float64 and pos.is_contiguous()
+        assert cnt is None or (cnt.is_cuda and cnt.dtype == torch.int64 and cnt.is_contiguous() and cnt.numel() == pos.numel())
+        self._nv.check(self._nv.lib.mc_allreduce_rank(
+            self._h, C.c_void_p(pos.data_ptr()), C.c_void_p(cnt.data_ptr()) if cnt is not None else None,
+            pos.numel(), C.c_void_p(torch.cuda.current_stream(pos.device).cuda_stream)))
+        return pos
+
+    def close(self):
+        if self._h:
+            self._nv.lib.mc_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 def raise_on_poisoned(pos: torch.Tensor) -> None:
     """A rank build that failed on ANY shard poisons that shard's positions with NaN (csrc/mc_rank.hip: error
     word); NaN survives the SUM, so every rank sees it here.  It must not be read as "no sample counted"

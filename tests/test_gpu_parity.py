@@ -370,6 +370,27 @@ def test_gc_columns_and_native_write2(big_model):
     assert buf.getvalue().split("\n")[0] == "changed\t1.00000000\t2\t3\t4\t 5.00"
 
 
+def test_c_abi_collective_on_one_rank():
+    """mc_comm_unique_id / mc_comm_init / mc_allreduce_rank / mc_comm_destroy (RCCL bound at run time) with a
+    world of one rank -- what a 1-GPU box can run: the sum over one rank leaves positions and counts as they
+    are, twice in a row, on the caller's stream.  (More ranks need more GPUs: RCCL refuses two ranks on one
+    device; the sum itself is covered over gloo in tests/test_dist_gloo.py.)"""
+    from montecarlo_amd.dist import NativeComm
+    comm = NativeComm(NativeComm.unique_id(), 0, 1)
+    g = torch.Generator().manual_seed(2)
+    pos = (torch.rand(100001, generator=g, dtype=torch.float64) * 1e12).cuda()
+    cnt = torch.randint(0, 1 << 40, (100001,), generator=g, dtype=torch.int64).cuda()
+    want_p, want_c = pos.clone(), cnt.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        comm.combine(pos, cnt)
+        comm.combine(pos)
+    side.synchronize()
+    assert torch.equal(pos, want_p) and torch.equal(cnt, want_c)
+    comm.close()
+
+
 def test_order_keys_is_pythons_stable_sort():
     """mc_order_keys == sorted(range(t), key=x.__getitem__) (lib4mc/MonteCarloParent.py:68): ties keep their
     input order, -0.0 ties with 0.0, unparseable scores (1022.0) and inf sort where Python puts them."""

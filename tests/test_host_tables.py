@@ -527,6 +527,12 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_device():
     rejected(lib.mc_order_keys(a, 2 ** 32, b, c, big, 1 << 62, None), "2\\^32")
     rejected(lib.mc_order_keys(a, 10, b, c, big, oneed - 1, None), "workspace")
     rejected(lib.mc_guess_numbers(a, None, 10, 1, b, None, big, 1 << 20, None), "mc_guess_numbers")
+    h = ctypes.c_void_p()
+    rejected(lib.mc_comm_init(None, 0, 1, ctypes.byref(h)), "mc_comm_init")
+    rejected(lib.mc_comm_init(a, 2, 2, ctypes.byref(h)), "mc_comm_init")             # rank outside the world
+    rejected(lib.mc_comm_unique_id(None), "mc_comm_unique_id")
+    rejected(lib.mc_allreduce_rank(None, a, None, 10, None), "mc_allreduce_rank")
+    lib.mc_comm_destroy(None)                                                        # nothing to do
     rejected(lib.mc_rank_query(a, b, 10, None, 5, c, None, None), "mc_rank_query")
     rejected(lib.mc_rank_query(None, b, 10, a, 5, c, None, None), "mc_rank_query")
     rejected(lib.mc_sample(None, 0, 10, 1, 100, a, None, None, None, 0, None), "mc_sample")

@@ -87,14 +87,6 @@ def id_plan(world: int, steps: int, n: int):
     return plan
 
 
-class _NoEvent:
-    def record(self, *a):
-        pass
-
-    def elapsed_time(self, other):
-        return 1e-9
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,7 +111,6 @@ def main():
     ap.add_argument("--dry", action="store_true",
                     help="no GPU: check the sample-id plan of a --gpus N run (every rank and step draws its own "
                          "range of Philox ids, n_global = N x samples) and print it")
-    ap.add_argument("--bare", action="store_true", help=argparse.SUPPRESS)   # experiment: no stage events
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="rehearsal of the multi-rank control flow on a 1-GPU box: every rank uses cuda:0 and the "
                          "collective runs over gloo (the printed numbers mean nothing)")
@@ -197,8 +188,7 @@ def main():
     def step(it: int, timed: bool):
         """sample -> rank build -> [score -> order] -> queries -> guess numbers; the bracketed part runs on a
         second stream from the start of the step unless --serial, the copies to the host on a third."""
-        marks = [torch.cuda.Event(enable_timing=True) if not args.bare or i in (6, 8, 11) else _NoEvent()
-                 for i in range(12)]
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(12)]
         slot = it & 1
         first = first_id(it, world, rank, N)                # disjoint Philox sample ids per rank and step
         marks[0].record()

@@ -361,7 +361,7 @@ def main():
             # the rank build as a whole (csrc/mc_sort.hip's launches + weight sums + positions, timed together)
             # against the 40 B/key a sort-and-scan cannot do without
             "roofline_rank_build": {"bound": "hbm", "kernel": "mc_rank_build (k_sniff, k_strip, k_scatter, k_count, "
-                                    "k_finish, k_fill, k_weight_sums, k_positions)", "achieved": rank_achieved,
+                                    "k_deep, k_finish, k_fill, k_weight_sums, k_positions)", "achieved": rank_achieved,
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rank_achieved / HBM_PEAK_GBS,
                                     "traffic": TRAFFIC.get("mc_rank_build"), "bytes_per_launch": rank_bytes,
                                     "kernel_ms": ms["rank"], "sort": sort_info},

@@ -90,8 +90,8 @@ def id_plan(world: int, steps: int, n: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)       # (0.3 s of steps: one stall of a few ms -- seen on
+    ap.add_argument("--warmup", type=int, default=10)       # fresh boxes -- does not decide a 20-step figure)
     ap.add_argument("--samples", type=int, default=10_000_000, help="samples per GPU per step")
     ap.add_argument("--tests", type=int, default=1_000_000)
     ap.add_argument("--train-lines", type=int, default=100_000)
@@ -285,8 +285,10 @@ def main():
     dm.check()                                              # clears counters; raises on a diverged sample
     fence()
     t0 = time.perf_counter()
+    host_t = []
     for s in range(args.steps):
         step(args.warmup + s, True)
+        host_t.append(time.perf_counter() - t0)
     issued = time.perf_counter() - t0                       # the host's share: launching, not waiting
     fence()
     dt = time.perf_counter() - t0
@@ -345,6 +347,8 @@ def main():
                        "entries": int(flat.info[nv.INFO_NENT]), "table_bytes": int(flat.info[nv.INFO_DEVICE_BYTES])},
             "stage_ms": ms, "test_set_on_second_stream": side is not None,
             "host_issue_ms_per_step": issued / args.steps * 1e3,
+            "step_starts_ms": [round(ev["sample"][0][0].elapsed_time(e[0]), 3) for e in ev["sample"]][:40],
+            "host_issue_done_ms": [round(t * 1e3, 3) for t in host_t][:40],
             "sampling_only_per_s": N * world / (ms["sample"] * 1e-3),
             # score + stable order + bisection + monotone guess numbers (device time of those four stages); the
             # copy of ranks/order/scores to the host (`d2h` in stage_ms) runs beside the next step

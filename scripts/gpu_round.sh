@@ -21,7 +21,7 @@ for s in $STEPS; do
         > "$OUT/gpu_tests.log" 2>&1 || { rc=$?; tail -30 "$OUT/gpu_tests.log"; die tests $rc; }
       tail -3 "$OUT/gpu_tests.log" ;;
     bench)
-      timeout -k 10 400 python3 bench.py --steps 10 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err" \
+      timeout -k 10 400 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" \
         || { rc=$?; tail -20 "$OUT/bench.err"; die bench $rc; }
       cat "$OUT/bench.json" ;;
     prof)

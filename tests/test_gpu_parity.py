@@ -370,6 +370,28 @@ def test_gc_columns_and_native_write2(big_model):
     assert buf.getvalue().split("\n")[0] == "changed\t1.00000000\t2\t3\t4\t 5.00"
 
 
+def test_driver_flow_edge_sizes(big_model):
+    """Empty, one-line, two-equal-lines and just-over-the-native-writer's-threshold test files through
+    parse_file -> ml2p_iter2gc -> write2: the native-ingest route and the reference's line loop (taken for a text
+    with '\\r') give the same lists and the same bytes."""
+    m, _ = big_model
+    m.seed(13)
+    mc = MonteCarloLib(m.sample(50000))
+    words = synth.zipf_corpus(700, oov_frac=0.05, stream=5)
+    for lines in ([], ["password1"], ["abc123", "abc123"], [""], words[:3], words[:513], words):
+        outs = []
+        for sep in ("\n", "\r\n"):
+            text = sep.join(lines) + (sep if lines else "")
+            scored = m.parse_file(io.StringIO(text, newline=""))
+            gc = mc.ml2p_iter2gc(scored)
+            buf = io.StringIO()
+            mc.write2(buf)
+            outs.append((list(scored), list(gc), buf.getvalue()))
+        assert outs[0] == outs[1], len(lines)
+        assert sum(c for _, c, _ in outs[0][0]) == len(lines)
+        assert outs[0][2].count("\n") == len(set(lines))
+
+
 def test_c_abi_collective_on_one_rank():
     """mc_comm_unique_id / mc_comm_init / mc_allreduce_rank / mc_comm_destroy (RCCL bound at run time) with a
     world of one rank -- what a 1-GPU box can run: the sum over one rank leaves positions and counts as they

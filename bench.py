@@ -350,6 +350,9 @@ def main():
             "step_starts_ms": [round(ev["sample"][0][0].elapsed_time(e[0]), 3) for e in ev["sample"]][:40],
             "host_issue_done_ms": [round(t * 1e3, 3) for t in host_t][:40],
             "sampling_only_per_s": N * world / (ms["sample"] * 1e-3),
+            # the step as round 1 defined it (sample + rank build + score + bisection, nothing ordered, ranked or
+            # copied), from the same launches' stage times: the figure to hold against round 1's 9.6e9
+            "round1_step_samples_per_s": N * world / ((ms["sample"] + ms["rank"] + ms["score"] + ms["query"]) * 1e-3),
             # score + stable order + bisection + monotone guess numbers (device time of those four stages); the
             # copy of ranks/order/scores to the host (`d2h` in stage_ms) runs beside the next step
             "guess_numbers_per_s": T / (gn_ms * 1e-3),

@@ -50,13 +50,28 @@ __global__ void __launch_bounds__(256) k_order_prep(const u64 *__restrict__ x, u
         keys[p] = order_bits(x[p]);
 }
 
-// words[p] = (index of the first sorted key equal to x[p]'s) << 32 | p
-__global__ void __launch_bounds__(256) k_order_words(const u64 *__restrict__ sorted, const u64 *__restrict__ x, u64 t,
-                                                     u64 *__restrict__ words, const u32 *sort_err, u32 *failed) {
+// words[p] = (index of the first sorted key equal to x[p]'s) << 32 | p.  The search runs in two stages: every
+// OW_STRIDE-th sorted key is staged in LDS and searched there, the rest of the search is confined to one stride of
+// the sorted array (20 dependent reads from memory per password were most of this kernel's time).
+constexpr int OW_THREADS = 256, OW_LDS = 4096;
+
+__global__ void __launch_bounds__(OW_THREADS) k_order_words(const u64 *__restrict__ sorted, const u64 *__restrict__ x,
+                                                            u64 t, u32 stride, u64 *__restrict__ words,
+                                                            const u32 *sort_err, u32 *failed) {
+    __shared__ u64 top[OW_LDS];
     if (blockIdx.x == 0 && threadIdx.x == 0) *failed = *sort_err;  // (the second sort clears the sort's own word)
+    const u32 nt = (u32)((t + stride - 1) / stride);  // <= OW_LDS by the caller's choice of stride
+    for (u32 i = threadIdx.x; i < nt; i += OW_THREADS) top[i] = sorted[(u64)i * stride];
+    __syncthreads();
     for (u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x; p < t; p += (u64)gridDim.x * blockDim.x) {
         const u64 v = order_bits(x[p]);
-        u64 lo = 0, hi = t;  // first index with sorted[i] >= v
+        // the last staged key below v: the first key >= v lies after it, at most one stride further
+        u32 a = 0, b = nt;  // first staged index with top[i] >= v
+        while (a < b) {
+            const u32 mid = (a + b) >> 1;
+            if (top[mid] < v) a = mid + 1; else b = mid;
+        }
+        u64 lo = a ? (u64)(a - 1) * stride + 1 : 0, hi = (u64)a * stride < t ? (u64)a * stride : t;
         while (lo < hi) {
             const u64 mid = (lo + hi) >> 1;
             if (sorted[mid] < v) lo = mid + 1; else hi = mid;
@@ -219,8 +234,12 @@ extern "C" int mc_order_keys(const double *x, uint64_t t, double *x_sorted, uint
     hipLaunchKernelGGL(k_order_prep, dim3(g), dim3(256), 0, s, (const u64 *)x, (u64)t, words_sorted);
     int rc = mc_sort_keys((const uint64_t *)words_sorted, t, (uint64_t *)x_sorted, workspace, sort_bytes, &err1, 0, s);
     if (rc != MC_OK) return rc;
-    hipLaunchKernelGGL(k_order_words, dim3(g), dim3(256), 0, s, (const u64 *)x_sorted, (const u64 *)x, (u64)t, words,
-                       (const u32 *)err1, failed);
+    {
+        const u32 stride = (u32)((t + OW_LDS - 1) / OW_LDS);  // (t < 2^32: at most 2^20 keys a stride)
+        const u32 gw = (u32)((t + 2047) / 2048 < 512 ? (t + 2047) / 2048 : 512);
+        hipLaunchKernelGGL(k_order_words, dim3(gw), dim3(OW_THREADS), 0, s, (const u64 *)x_sorted, (const u64 *)x,
+                           (u64)t, stride ? stride : 1u, words, (const u32 *)err1, failed);
+    }
     rc = mc_sort_keys((const uint64_t *)words, t, (uint64_t *)words_sorted, workspace, sort_bytes, &err2,
                       MC_SORT_FEW_REPEATS /* the words are distinct */, s);
     if (rc != MC_OK) return rc;

@@ -10,6 +10,7 @@ C-ABI of libmi355mc.so (montecarlo_amd._native via the host classes):
      plus bit-exact agreement with the C oracle on larger runs.
 """
 import io
+import os
 from math import ceil
 
 import numpy as np
@@ -665,6 +666,30 @@ def test_rank_key_distributions():
         if name != "all bit patterns":                       # (there the weights overflow: 2 ** 1e308)
             ref = torch.cumsum(torch.exp2(srt - np.log2(n)), 0)
             assert float(((rk.positions - ref).abs() / ref).max()) < REL, name
+
+
+def test_sort_and_order_fuzz():
+    """Differential fuzz (scripts/sort_fuzz.py: random sizes up to 3e6, random mixtures of ties, clusters at several
+    scales, single-bit keys, full bit patterns, runs, order words) of the key sort and of mc_order_keys against
+    torch.sort; 80 seeded cases here, thousands when the script is run by hand."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("sort_fuzz", os.path.join(root, "scripts", "sort_fuzz.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    from montecarlo_amd.engine import device_order
+    g = torch.Generator().manual_seed(2024)
+    for c in range(80):
+        n = int(10 ** (torch.rand(1, generator=g).item() * 6.5)) + 1
+        x, kind = fz.make(g, n)
+        xd = x.cuda()
+        rk = DeviceRank(xd)
+        assert rk.check()["error"] == 0
+        assert torch.equal(rk.keys_sorted.view(torch.int64), torch.sort(xd.view(torch.int64))[0]), (c, kind, n)
+        srt, order = device_order(xd)
+        want = torch.sort(xd, stable=True)
+        assert torch.equal(order.long() & 0xFFFFFFFF, want[1]), (c, kind, n)
+        assert torch.equal(srt.view(torch.int64), want[0].view(torch.int64)), (c, kind, n)
 
 
 def test_distribution_vs_reference_sampler(train_char):

@@ -55,6 +55,7 @@ __global__ void __launch_bounds__(256) k_order_prep(const u64 *__restrict__ x, u
 // the sorted array (20 dependent reads from memory per password were most of this kernel's time).
 constexpr int OW_THREADS = 256, OW_LDS = 4096;
 
+template <bool WORDS>  // WORDS: 64-bit words for a second key sort; else only the 32-bit index L, for the LSD passes
 __global__ void __launch_bounds__(OW_THREADS) k_order_words(const u64 *__restrict__ sorted, const u64 *__restrict__ x,
                                                             u64 t, u32 stride, u64 *__restrict__ words,
                                                             const u32 *sort_err, u32 *failed) {
@@ -76,7 +77,151 @@ __global__ void __launch_bounds__(OW_THREADS) k_order_words(const u64 *__restric
             const u64 mid = (lo + hi) >> 1;
             if (sorted[mid] < v) lo = mid + 1; else hi = mid;
         }
-        words[p] = (lo << 32) | p;
+        if (WORDS) words[p] = (lo << 32) | p;
+        else ((u32 *)words)[p] = (u32)lo;
+    }
+}
+
+// ---- stable LSD radix passes over (L, index) ---------------------------------------------------------------
+// The second half of the stable order for up to 2^24 passwords: the pairs (L = index of the first sorted key equal
+// to the password's, password index) are sorted by L with the indices kept in their order -- three passes of up to
+// 8 bits, each three launches and no workgroup waiting for another: per-tile digit histograms, their prefix over the
+// tiles, and a scatter that ranks a tile's elements in index order (a wave finds the lanes that share its digit
+// with one ballot per digit bit; the waves' 64-element chunks of a tile are prefixed in LDS).  A keys-only sort of
+// the words `L << 32 | index` does the same (and still does above 2^24) at three times the cost: it cannot use
+// that the indices arrive in order.
+constexpr int LS_THREADS = 512, LS_ROUNDS = 4, LS_TILE = LS_THREADS * LS_ROUNDS, LS_CHUNKS = LS_TILE / 64;
+constexpr u64 LS_MAX_T = 1ull << 24;
+
+__global__ void __launch_bounds__(LS_THREADS) k_lsd_hist(const u32 *__restrict__ key, u64 t, u32 shift, u32 mask,
+                                                         u32 tiles, u32 *__restrict__ table) {
+    __shared__ u32 h[256];
+    const u32 tile = blockIdx.x;
+    if (threadIdx.x < 256) h[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < LS_ROUNDS; ++r) {
+        const u64 j = (u64)tile * LS_TILE + r * LS_THREADS + threadIdx.x;
+        if (j < t) atomicAdd(&h[(key[j] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) table[(u64)threadIdx.x * tiles + tile] = h[threadIdx.x];
+}
+
+// table[bin][tile] -> exclusive prefix over the tiles of the bin, totals[bin] = the bin's size (one workgroup a bin)
+__global__ void __launch_bounds__(256) k_lsd_scan(u32 *__restrict__ table, u32 tiles, u32 *__restrict__ totals) {
+    __shared__ u32 wsum[4];
+    u32 *row = table + (u64)blockIdx.x * tiles;
+    const u32 per = (tiles + 255) / 256;
+    const u32 lo = threadIdx.x * per < tiles ? threadIdx.x * per : tiles, hi = lo + per < tiles ? lo + per : tiles;
+    u32 sum = 0;
+    for (u32 i = lo; i < hi; ++i) sum += row[i];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    u32 inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+    }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    u32 off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w < wid) off += wsum[w];
+        tot += wsum[w];
+    }
+    u32 run = off + inc - sum;
+    for (u32 i = lo; i < hi; ++i) {
+        const u32 v = row[i];
+        row[i] = run;
+        run += v;
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(LS_THREADS) k_lsd_scatter(const u32 *__restrict__ key, const u32 *__restrict__ pay,
+                                                            u64 t, u32 shift, u32 mask, int bits, u32 tiles,
+                                                            const u32 *__restrict__ table, const u32 *__restrict__ totals,
+                                                            u32 *__restrict__ key_out, u32 *__restrict__ pay_out) {
+    __shared__ unsigned short cc[LS_CHUNKS][256];  // elements of each 64-element chunk per digit, then their prefix
+    __shared__ u32 gb[256];
+    __shared__ u32 wsum[LS_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const u32 tile = blockIdx.x;
+    for (int i = tid; i < LS_CHUNKS * 256 / 2; i += LS_THREADS) ((u32 *)cc)[i] = 0;
+    {   // first place of every digit in the output + this tile's places after the earlier tiles'
+        const u32 v = tid < 256 ? totals[tid] : 0u;
+        u32 inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        if (lane == 63) wsum[wid] = inc;
+        __syncthreads();
+        u32 off = 0;
+        for (int w = 0; w < wid; ++w) off += wsum[w];
+        if (tid < 256) gb[tid] = off + inc - v + table[(u64)tid * tiles + tile];
+    }
+    __syncthreads();
+    const u64 lt = (1ull << lane) - 1ull;
+    u32 k[LS_ROUNDS], p[LS_ROUNDS], rnk[LS_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < LS_ROUNDS; ++r) {
+        const u64 j = (u64)tile * LS_TILE + r * LS_THREADS + tid;
+        const bool act = j < t;
+        k[r] = act ? key[j] : 0u;
+        p[r] = act ? (pay ? pay[j] : (u32)j) : 0u;
+        const u32 d = (k[r] >> shift) & mask;
+        u64 m = __ballot(act);  // the active lanes that share this lane's digit
+        for (int b = 0; b < bits; ++b) {
+            const bool one = (d >> b) & 1u;
+            const u64 bal = __ballot(act && one);
+            m &= one ? bal : ~bal;
+        }
+        rnk[r] = (u32)__popcll(m & lt);
+        if (act && rnk[r] == 0) cc[r * (LS_THREADS / 64) + wid][d] = (unsigned short)__popcll(m);
+    }
+    __syncthreads();
+    if (tid < 256) {  // exclusive prefix over the tile's chunks, in index order
+        u32 run = 0;
+#pragma unroll 8
+        for (int c = 0; c < LS_CHUNKS; ++c) {
+            const u32 v = cc[c][tid];
+            cc[c][tid] = (unsigned short)run;
+            run += v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < LS_ROUNDS; ++r) {
+        const u64 j = (u64)tile * LS_TILE + r * LS_THREADS + tid;
+        if (j < t) {
+            const u32 d = (k[r] >> shift) & mask;
+            const u64 at = (u64)gb[d] + cc[r * (LS_THREADS / 64) + wid][d] + rnk[r];
+            if (at < t) {  // (always: the histogram counted these same keys)
+                if (key_out) key_out[at] = k[r];
+                pay_out[at] = p[r];
+            }
+        }
+    }
+}
+
+// order[i] = the LSD passes' i-th index, x_sorted[i] = the caller's own bits of that password's key
+__global__ void __launch_bounds__(256) k_order_out32(const u32 *__restrict__ idx, const u64 *__restrict__ x, u64 t,
+                                                     u32 *__restrict__ order, u64 *__restrict__ x_sorted,
+                                                     const u32 *failed) {
+    const bool bad = *failed != 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < t; i += (u64)gridDim.x * blockDim.x) {
+        if (bad) {  // the key sort gave up: no order at all rather than a wrong one
+            order[i] = 0xFFFFFFFFu;
+            x_sorted[i] = 0x7FF8000000000000ull;
+            continue;
+        }
+        const u32 o = idx[i];
+        order[i] = o;
+        x_sorted[i] = x[o];
     }
 }
 
@@ -234,12 +379,37 @@ extern "C" int mc_order_keys(const double *x, uint64_t t, double *x_sorted, uint
     hipLaunchKernelGGL(k_order_prep, dim3(g), dim3(256), 0, s, (const u64 *)x, (u64)t, words_sorted);
     int rc = mc_sort_keys((const uint64_t *)words_sorted, t, (uint64_t *)x_sorted, workspace, sort_bytes, &err1, 0, s);
     if (rc != MC_OK) return rc;
-    {
-        const u32 stride = (u32)((t + OW_LDS - 1) / OW_LDS);  // (t < 2^32: at most 2^20 keys a stride)
-        const u32 gw = (u32)((t + 2047) / 2048 < 512 ? (t + 2047) / 2048 : 512);
-        hipLaunchKernelGGL(k_order_words, dim3(gw), dim3(OW_THREADS), 0, s, (const u64 *)x_sorted, (const u64 *)x,
-                           (u64)t, stride ? stride : 1u, words, (const u32 *)err1, failed);
+    const u32 stride = (u32)((t + OW_LDS - 1) / OW_LDS) ? (u32)((t + OW_LDS - 1) / OW_LDS) : 1u;  // (t < 2^32)
+    const u32 gw = (u32)((t + 2047) / 2048 < 512 ? (t + 2047) / 2048 : 512);
+    if (t <= LS_MAX_T) {
+        // (L, index) pairs through stable LSD passes; the buffers of the words hold two u32 arrays each, the
+        // digit tables take the head of the sort's workspace (the sort is over by then, its error word read)
+        u32 *ka = (u32 *)words, *pa = ka + t, *kb = (u32 *)words_sorted, *pb = kb + t;
+        const u32 tiles = (u32)((t + LS_TILE - 1) / LS_TILE);
+        u32 *table = (u32 *)workspace, *totals = table + (size_t)256 * tiles;
+        hipLaunchKernelGGL(k_order_words<false>, dim3(gw), dim3(OW_THREADS), 0, s, (const u64 *)x_sorted, (const u64 *)x,
+                           (u64)t, stride, words, (const u32 *)err1, failed);
+        int nbits = 1;
+        while (nbits < 32 && (t - 1) >> nbits) ++nbits;
+        const int passes = (nbits + 7) / 8, width = (nbits + passes - 1) / passes;
+        const u32 *kin = ka, *pin = nullptr;  // (first pass: the index is the position)
+        for (int ps = 0; ps < passes; ++ps) {
+            u32 *kout = (ps & 1) ? ka : kb, *pout = (ps & 1) ? pa : pb;
+            const u32 shift = (u32)(ps * width), mask = (1u << width) - 1u;
+            hipLaunchKernelGGL(k_lsd_hist, dim3(tiles), dim3(LS_THREADS), 0, s, kin, (u64)t, shift, mask, tiles, table);
+            hipLaunchKernelGGL(k_lsd_scan, dim3(256), dim3(256), 0, s, table, tiles, totals);
+            hipLaunchKernelGGL(k_lsd_scatter, dim3(tiles), dim3(LS_THREADS), 0, s, kin, pin, (u64)t, shift, mask, width,
+                               tiles, (const u32 *)table, (const u32 *)totals, ps + 1 < passes ? kout : (u32 *)nullptr, pout);
+            kin = kout;
+            pin = pout;
+        }
+        hipLaunchKernelGGL(k_order_out32, dim3(g), dim3(256), 0, s, pin, (const u64 *)x, (u64)t, order, (u64 *)x_sorted,
+                           (const u32 *)failed);
+        HIP_TRY(hipGetLastError());
+        return MC_OK;
     }
+    hipLaunchKernelGGL(k_order_words<true>, dim3(gw), dim3(OW_THREADS), 0, s, (const u64 *)x_sorted, (const u64 *)x,
+                       (u64)t, stride, words, (const u32 *)err1, failed);
     rc = mc_sort_keys((const uint64_t *)words, t, (uint64_t *)words_sorted, workspace, sort_bytes, &err2,
                       MC_SORT_FEW_REPEATS /* the words are distinct */, s);
     if (rc != MC_OK) return rc;

@@ -437,6 +437,12 @@ def test_order_keys_is_pythons_stable_sort():
         assert np.array_equal(srt.cpu().numpy().view(np.uint64), x[want].view(np.uint64)), name
     srt, order = device_order(torch.empty(0, dtype=torch.float64, device="cuda"))
     assert srt.numel() == 0 and order.numel() == 0
+    # above 2^24 keys the second half is a key sort of (L << 32 | index) words instead of the LSD passes
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randint(0, 3_000_000, (17_000_001,), generator=g).double() * 2.0 ** -10).cuda()
+    srt, order = device_order(x)
+    want = torch.sort(x, stable=True)
+    assert torch.equal(order.long() & 0xFFFFFFFF, want[1]) and torch.equal(srt, want[0])
 
 
 def test_guess_numbers_equal_reference_loop():

@@ -285,10 +285,8 @@ def main():
     dm.check()                                              # clears counters; raises on a diverged sample
     fence()
     t0 = time.perf_counter()
-    host_t = []
     for s in range(args.steps):
         step(args.warmup + s, True)
-        host_t.append(time.perf_counter() - t0)
     issued = time.perf_counter() - t0                       # the host's share: launching, not waiting
     fence()
     dt = time.perf_counter() - t0
@@ -347,8 +345,6 @@ def main():
                        "entries": int(flat.info[nv.INFO_NENT]), "table_bytes": int(flat.info[nv.INFO_DEVICE_BYTES])},
             "stage_ms": ms, "test_set_on_second_stream": side is not None,
             "host_issue_ms_per_step": issued / args.steps * 1e3,
-            "step_starts_ms": [round(ev["sample"][0][0].elapsed_time(e[0]), 3) for e in ev["sample"]][:40],
-            "host_issue_done_ms": [round(t * 1e3, 3) for t in host_t][:40],
             "sampling_only_per_s": N * world / (ms["sample"] * 1e-3),
             # the step as round 1 defined it (sample + rank build + score + bisection, nothing ordered, ranked or
             # copied), from the same launches' stage times: the figure to hold against round 1's 9.6e9

@@ -825,7 +825,7 @@ __global__ void __launch_bounds__(WG) k_scatter(Ws w, int level) {
 // and the cursors in LDS and the segments it splits off on a stack of its own (depth-first; a segment's subtree
 // touches nobody else's keys).  No launch per level, nothing to wait for.  Such segments are rare and small on
 // the keys this library sorts (a few clustered value ranges); a large input keeps more launched levels instead.
-__global__ void __launch_bounds__(WG) k_deep(Ws w, int level0, Seg *arena, u32 arena_cap) {
+__global__ void __launch_bounds__(WG, 4) k_deep(Ws w, int level0, Seg *arena, u32 arena_cap) {
     __shared__ u64 stage[TILE];
     __shared__ u32 hc[256];
     __shared__ u64 hor[256], hnor[256];
@@ -997,7 +997,7 @@ __device__ __forceinline__ void wave_sort(u64 *a, u32 g, int lane) {
     }
 }
 
-__global__ void __launch_bounds__(WG) k_finish(Ws w) {
+__global__ void __launch_bounds__(WG, 4) k_finish(Ws w) {  // (4 waves per SIMD = two workgroups a CU: 128 VGPRs)
     __shared__ u64 stage[CAP];
     __shared__ u32 start[BINS + 1];
     __shared__ u64 hv[H_MAX];
@@ -1013,6 +1013,20 @@ __global__ void __launch_bounds__(WG) k_finish(Ws w) {
     if (w.ctl->err) return;  // a table overflowed in an earlier kernel: the tile list is not to be trusted
     const u32 nft = w.ctl->nft < w.cap_ft ? w.ctl->nft : w.cap_ft;
     if (blockIdx.x >= nft) return;
+    // the first tile's keys are requested before anything else: they travel while the heavy values are set up
+    // (two dependent round trips to memory, the tile's entry and its keys, were a third of a tile's time)
+    u64 pre[ITEMS];
+    auto request = [&](u32 t) {  // the keys of tile t (tile entries are checked before they are believed)
+        const FTile f = w.ft[t];
+        const u32 m = f.off < w.n ? (f.size < (u32)CAP ? f.size : (u32)CAP) : 0u;
+        const u64 *src = (f.src == SRC_IN ? w.in : (f.src == SRC_B ? (const u64 *)w.B : (const u64 *)w.C)) + f.off;
+#pragma unroll
+        for (int q = 0; q < ITEMS; ++q) {
+            const u32 j = q * WG + tid;
+            pre[q] = j < m && (u64)f.off + j < (u64)w.n ? src[j] : 0ull;
+        }
+    };
+    request(blockIdx.x);
     // heavy values and the prefix sums of their copies
     {
         u32 c[2];
@@ -1045,8 +1059,7 @@ __global__ void __launch_bounds__(WG) k_finish(Ws w) {
     };
     for (u32 t = blockIdx.x; t < nft; t += gridDim.x) {
         const FTile f = w.ft[t];
-        const u32 m = f.size < (u32)CAP ? f.size : (u32)CAP;
-        const u64 *src = (f.src == SRC_IN ? w.in : (f.src == SRC_B ? (const u64 *)w.B : (const u64 *)w.C)) + f.off;
+        const u32 m = f.off < w.n ? (f.size < (u32)CAP ? f.size : (u32)CAP) : 0u;  // (as request() read it)
         u64 *out = w.A + f.off;
         const u64 room = (u64)w.n - f.off;  // a final index is < n; checked at every store
         u32 idx_lo = 0, idx_hi = 0;         // heavy values below the tile's smallest / largest key
@@ -1080,7 +1093,7 @@ __global__ void __launch_bounds__(WG) k_finish(Ws w) {
 #pragma unroll
             for (int q = 0; q < ITEMS; ++q) {
                 const u32 j = q * WG + tid;
-                k[q] = j < g0 ? (r == 0 ? src[j] : stage[s0 + j]) : 0ull;
+                k[q] = j < g0 ? (r == 0 ? pre[q] : stage[s0 + j]) : 0ull;
                 if (j < g0) {
                     mn = k[q] < mn ? k[q] : mn;
                     mx = k[q] > mx ? k[q] : mx;
@@ -1187,6 +1200,15 @@ __global__ void __launch_bounds__(WG) k_finish(Ws w) {
             const u32 nl = nlarge < (u32)LARGE_CAP ? nlarge : (u32)LARGE_CAP;
             for (u32 li = wid; li < nl; li += NWAVE) {
                 const u32 s = large[2 * li], g = large[2 * li + 1];
+                {   // one value (the usual large bucket: a score with tens to thousands of copies): a run
+                    const u64 v0 = stage[s];
+                    bool same = true;
+                    for (u32 i = lane; i < g; i += 64) same &= stage[s + i] == v0;
+                    if (__all(same)) {
+                        emit_run(s, v0, g, lane, 64);
+                        continue;
+                    }
+                }
                 // the PROBE smallest distinct values and their copies -- nothing is written until they are known
                 // to be all there is
                 u64 cand[PROBE];
@@ -1243,6 +1265,7 @@ __global__ void __launch_bounds__(WG) k_finish(Ws w) {
         }
         // (no heavy value inside the tile's range: all its keys have the same number of heavy values below)
         if (idx_lo == idx_hi && tid == 0) gapl[idx_lo] += m;
+        if (t + gridDim.x < nft) request(t + gridDim.x);
     }
     __syncthreads();
     for (u32 i = tid; i <= H; i += WG)

@@ -173,7 +173,7 @@ def main():
             for _ in range(2)]
     ws_order = torch.empty(nv.lib.mc_order_workspace_bytes(T), dtype=torch.uint8, device=dev)
     ws_gn = torch.empty(nv.lib.mc_guess_numbers_workspace_bytes(T), dtype=torch.uint8, device=dev)
-    reduced, copied = [None, None], [None, None]
+    reduced, copied, copied_on = [None, None], [None, None], [None, None]
     comm = torch.cuda.Stream(device=dev) if world > 1 else None
     copy = torch.cuda.Stream(device=dev)
     q_cnt = torch.empty(T, dtype=torch.int64, device=dev)
@@ -216,16 +216,18 @@ def main():
         marks[2].record()
         if side is None:
             if copied[slot] is not None:
-                main_stream.wait_event(copied[slot])
+                if copied_on[slot] is not main_stream:      # (a copy on this stream is behind us already)
+                    main_stream.wait_event(copied[slot])
                 copied[slot] = None
-            marks[3].record()
-            dm.score_device(d_syms, d_off, T, out=t_ml2p)
+            marks[3] = marks[2]                             # (one stream: a stage starts where the last one ended;
+            dm.score_device(d_syms, d_off, T, out=t_ml2p)   #  every recorded event is a barrier packet on the queue)
             marks[4].record()
             device_order(t_ml2p, out_sorted=t_sorted[slot], out_order=t_order[slot], workspace=ws_order)
             marks[6].record()
+            marks[5] = marks[6]
         else:
             main_stream.wait_event(marks[6])
-        marks[5].record()
+            marks[5].record()
         rk.query(t_sorted[slot], out_pos=q_pos[slot], out_cnt=q_cnt)
         marks[7].record()
         if comm is None:
@@ -251,9 +253,13 @@ def main():
                 reduced[slot] = marks[8]
             ready = marks[8]
         lane = copy if args.d2h == "overlap" else (comm if comm is not None else main_stream)
-        lane.wait_event(ready)
+        if lane is main_stream or lane is comm:
+            marks[10] = ready                               # (same stream as the guess numbers: nothing to wait for)
+        else:
+            lane.wait_event(ready)
         with torch.cuda.stream(lane):
-            marks[10].record()
+            if marks[10] is not ready:
+                marks[10].record()
             # the guess numbers travel every step (8 B per test password: they are what the samples decide); the
             # order of the test set and its sorted scores do not depend on the samples -- a caller fetches them
             # once per test set, here after the timed region for the checks (--d2h-all copies them every step)
@@ -263,7 +269,7 @@ def main():
                 host[slot]["order"].copy_(t_order[slot], non_blocking=True)
                 host[slot]["ml2p"].copy_(t_sorted[slot], non_blocking=True)
             marks[11].record()
-            copied[slot] = marks[11]
+            copied[slot], copied_on[slot] = marks[11], lane
         if timed:
             ev["sample"].append((marks[0], marks[1]))
             ev["rank"].append((marks[1], marks[2]))

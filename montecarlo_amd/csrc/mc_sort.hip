@@ -53,7 +53,7 @@ constexpr int TILE = 4096;         // keys per count / scatter tile
 constexpr int WG = 512;            // threads of the strip / count / scatter / finish workgroups
 constexpr int ITEMS = TILE / WG;   // keys per lane and tile
 constexpr int NWAVE = WG / 64;
-constexpr int REGION = 12288;      // keys per strip region (its tail is stored at the region's own offset)
+constexpr int STRIP_SLOTS = 512;   // k_strip workgroups a GPU holds at once (104 VGPRs: two a CU): regions are sized for ONE round of them
 constexpr int SNIFF_S = 16384, SNIFF_SLOTS = 16384, SNIFF_MIN = 5, SNIFF_THREADS = 1024, SNIFF_PROBES = 8;
 constexpr int H_MAX = 1024, HSET = 2048;
 constexpr int COPIES = 4;          // lane-sliced copies of LDS histograms: lanes l, l+4, ... share one
@@ -107,7 +107,7 @@ struct Ws {
     FTile *ft;
     const u64 *in;
     u64 *A, *B, *C;
-    u32 n, regions;
+    u32 n, region, regions;
     u32 cap_seg, cap_tile, cap_ft;
 };
 
@@ -395,8 +395,8 @@ __global__ void __launch_bounds__(WG) k_strip(Ws w) {
     u64 o = 0, no = 0;
     u32 tail_total = 0;  // (thread 0)
     for (u32 r = blockIdx.x; r < w.regions; r += gridDim.x) {
-        const u64 lo = (u64)r * REGION;
-        const u32 rn = (u32)(n - lo < (u64)REGION ? n - lo : (u64)REGION);
+        const u64 lo = (u64)r * w.region;
+        const u32 rn = (u32)(n - lo < (u64)w.region ? n - lo : (u64)w.region);
         if (tid == 0) roff = 0;
         __syncthreads();
         u64 k[ITEMS], nk[ITEMS];
@@ -748,7 +748,7 @@ __global__ void __launch_bounds__(WG) k_scatter(Ws w, int level) {
         u32 tile_lo, tile_hi;  // key range of this item inside `src`, in steps of TILE
         u64 base_in;
         if (ROOT) {
-            base_in = (u64)it * REGION;
+            base_in = (u64)it * w.region;
             tile_lo = 0;
             tile_hi = w.rcnt[it];
         } else {
@@ -1372,13 +1372,20 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Layout {
     size_t B, C, ctl, heavy, hcnt, gap, root, rcnt, segs[2], rows[2], tiles[2], ft, end;
-    u32 regions, cap_seg, cap_tile, cap_ft;
+    u32 region, regions, cap_seg, cap_tile, cap_ft;
     size_t clear_from, clear_bytes;
 };
 
 Layout layout_for(u64 n) {
     Layout L;
-    L.regions = (u32)((n + REGION - 1) / REGION);
+    // keys per strip region (its tail is stored at the region's own offset): whole tiles, as few as give every
+    // k_strip workgroup the GPU holds at once one region -- 814 regions of three tiles were a round of 512 and one of 302
+    {
+        const u64 tiles = (n + TILE - 1) / TILE;
+        const u64 per = (tiles + STRIP_SLOTS - 1) / STRIP_SLOTS;
+        L.region = (u32)((per ? per : 1) * TILE);
+    }
+    L.regions = (u32)((n + L.region - 1) / L.region);
     L.cap_seg = (u32)(n / CAP + 2);
     L.cap_tile = (u32)(n / TILE + L.cap_seg + 2);
     L.cap_ft = (u32)(3 * (n / CAP) + 3 * (u64)MAX_LEVELS * (n / CAP + 2) + 64);
@@ -1434,6 +1441,7 @@ int mc_sort_keys(const uint64_t *in, uint64_t n, uint64_t *out, void *workspace,
     w.B = (u64 *)(base + L.B);
     w.C = (u64 *)(base + L.C);
     w.n = (u32)n;
+    w.region = L.region;
     w.regions = L.regions;
     w.cap_seg = L.cap_seg;
     w.cap_tile = L.cap_tile;

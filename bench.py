@@ -90,8 +90,10 @@ def id_plan(world: int, steps: int, n: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)       # (0.3 s of steps: one stall of a few ms -- seen on
-    ap.add_argument("--warmup", type=int, default=10)       # fresh boxes -- does not decide a 20-step figure)
+    # (2.5 s of steps by default: a 20-step run is decided by one stall of a few ms, and the first few hundred steps
+    # on a fresh box run 0.1-0.2 ms slower than the steady state -- 1.33-1.46 ms over 200 steps, 1.21 over 5000)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--samples", type=int, default=10_000_000, help="samples per GPU per step")
     ap.add_argument("--tests", type=int, default=1_000_000)
     ap.add_argument("--train-lines", type=int, default=100_000)

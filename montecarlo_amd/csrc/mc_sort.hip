@@ -202,24 +202,33 @@ __global__ void __launch_bounds__(SNIFF_THREADS) k_sniff(Ws w) {
         const u32 block = (u32)((q * SNIFF_THREADS + tid) / BLOCK);
         k[q] = w.in[(u64)block * bstride + (u32)(tid % BLOCK)];
     }
+    // every key tries its home slot first, all PER attempts in flight together (one after the other they were PER
+    // dependent LDS round trips); only a key that finds another value there walks on
+    u32 tg[PER], old[PER];
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         const u32 x = sniff_mix(k[q]);
-        const u32 t = x | 1u;
-        u32 s = x >> 18;
-        slot[q] = 0xFFFFFFFFu;
+        tg[q] = x | 1u;
+        slot[q] = x >> 18;
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) old[q] = atomicCAS(&tag[slot[q]], 0u, tg[q]);
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
         // a sample that finds no place within SNIFF_PROBES slots is dropped: with few repeated values the table
         // fills up (as many samples as slots) and an unbounded probe would walk most of it for every sample
-        for (int probe = 0; probe < SNIFF_PROBES; ++probe) {
-            const u32 old = atomicCAS(&tag[s], 0u, t);
-            if (old == 0u || old == t) {
-                atomicAdd(&tc[s >> 1], 1u << (16 * (s & 1u)));
-                slot[q] = s;
-                break;
-            }
+        u32 s = slot[q];
+        bool placed = old[q] == 0u || old[q] == tg[q];
+        for (int probe = 1; !placed && probe < SNIFF_PROBES; ++probe) {
             s = (s + 1) & (SNIFF_SLOTS - 1);
+            const u32 o = atomicCAS(&tag[s], 0u, tg[q]);
+            placed = o == 0u || o == tg[q];
         }
+        slot[q] = placed ? s : 0xFFFFFFFFu;
     }
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+        if (slot[q] != 0xFFFFFFFFu) atomicAdd(&tc[slot[q] >> 1], 1u << (16 * (slot[q] & 1u)));
     u32 bar = SNIFF_MIN;
     for (;;) {  // (uniform: every thread sees the same nlist)
         __syncthreads();
@@ -235,11 +244,16 @@ __global__ void __launch_bounds__(SNIFF_THREADS) k_sniff(Ws w) {
     __syncthreads();
     if (tid == 0) nlist = 0;
     __syncthreads();
+    bool over[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {  // (the reads of all PER first, then the claims)
+        const u32 s = slot[q];
+        over[q] = s != 0xFFFFFFFFu && ((tc[s >> 1] >> (16 * (s & 1u))) & 0xFFFFu) >= bar;
+    }
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
-        const u32 s = slot[q];
-        if (s != 0xFFFFFFFFu && ((tc[s >> 1] >> (16 * (s & 1u))) & 0xFFFFu) >= bar) {
-            const u32 bit = 1u << (s & 31u);
+        if (over[q]) {
+            const u32 s = slot[q], bit = 1u << (s & 31u);
             if (!(atomicOr(&claim[s >> 5], bit) & bit)) {
                 const u32 p = atomicAdd(&nlist, 1u);
                 list[p] = k[q];  // one claim per slot, at most H_MAX slots at the bar
@@ -248,11 +262,25 @@ __global__ void __launch_bounds__(SNIFF_THREADS) k_sniff(Ws w) {
     }
     __syncthreads();
     const u32 H = nlist;
-    for (u32 i = tid; i < H; i += SNIFF_THREADS) {  // the values are distinct: rank = position
-        const u64 v = list[i];
-        u32 r = 0;
-        for (u32 j = 0; j < H; ++j) r += list[j] < v ? 1u : 0u;
-        w.heavy[r] = v;
+    // the values are distinct: rank = position.  All lanes take part: a value's comparisons are split over
+    // SNIFF_THREADS / H_MAX ... lanes when there are few values (one lane a value walked the whole list alone)
+    {
+        u32 *rank = tc;  // (the counts are not needed any more)
+        for (u32 i = tid; i < H; i += SNIFF_THREADS) rank[i] = 0;
+        __syncthreads();
+        u32 parts = 1;
+        while (parts * 2 * H <= (u32)SNIFF_THREADS && parts < 16) parts *= 2;
+        const u32 i = tid / parts, part = tid % parts;
+        if (i < H) {
+            const u64 v = list[i];
+            const u32 per = (H + parts - 1) / parts, j0 = part * per, j1 = j0 + per < H ? j0 + per : H;
+            u32 r = 0;
+#pragma unroll 8
+            for (u32 j = j0; j < j1; ++j) r += list[j] < v ? 1u : 0u;
+            if (r) atomicAdd(&rank[i], r);
+        }
+        __syncthreads();
+        for (u32 i2 = tid; i2 < H; i2 += SNIFF_THREADS) w.heavy[rank[i2]] = list[i2];
     }
     if (tid == 0) w.ctl->n_heavy = H;
 }

@@ -6,8 +6,8 @@ guess-number hot path on one GPU:
     sample N=1e7 strings (k_sample) -> sort + prefix sum of 1/(n p) (mc_rank_build)
     -> score T=1e6 test passwords (k_score) -> their stable order by -log2 p (mc_order_keys)
     -> bisect them into the curve (k_query)
-    [-> all-reduce of the per-test partial sums when world_size > 1, on its own stream beside the
-        next step's sampling]
+    [-> all-reduce of the per-test partial sums when world_size > 1 (in the step's order; --overlap-comm puts
+        it, the guess numbers and the copy on a stream of their own beside the next step's sampling)]
     -> monotone guess numbers (mc_guess_numbers) -> the guess numbers to pinned host memory (8 B per test
        password, inside the step; --d2h-all adds the order and the sorted scores)
 
@@ -103,6 +103,9 @@ def main():
                          "sampling and the rank build; measured slower than one stream (1.71 vs 1.56 ms a step: the "
                          "sampler fills the chip, the small launches only wait longer)")
     ap.add_argument("--serial", action="store_true", help=argparse.SUPPRESS)         # (the default)
+    ap.add_argument("--overlap-comm", action="store_true",
+                    help="world > 1: all-reduce, guess numbers and copy on a stream of their own beside the next "
+                         "step's sampling (the default keeps them in the step's own order)")
     ap.add_argument("--d2h", choices=("overlap", "inline"), default="inline",
                     help="copy of the guess numbers to the host: on the main stream inside the step (default: 1.56 ms "
                          "a step, the same from run to run) or on a copy stream beside the next step (1.66 ms: the "
@@ -176,7 +179,7 @@ def main():
     ws_order = torch.empty(nv.lib.mc_order_workspace_bytes(T), dtype=torch.uint8, device=dev)
     ws_gn = torch.empty(nv.lib.mc_guess_numbers_workspace_bytes(T), dtype=torch.uint8, device=dev)
     reduced, copied, copied_on = [None, None], [None, None], [None, None]
-    comm = torch.cuda.Stream(device=dev) if world > 1 else None
+    comm = torch.cuda.Stream(device=dev) if world > 1 and args.overlap_comm else None
     copy = torch.cuda.Stream(device=dev)
     q_cnt = torch.empty(T, dtype=torch.int64, device=dev)
     seed = 20250304
@@ -232,8 +235,20 @@ def main():
             marks[5].record()
         rk.query(t_sorted[slot], out_pos=q_pos[slot], out_cnt=q_cnt)
         marks[7].record()
-        if comm is None:
+        if world == 1:
             device_guess_numbers(q_pos[slot], q_cnt, True, out=g_rank[slot], workspace=ws_gn, exact=g_exact[slot])
+            marks[8].record()
+            ready = marks[8]
+        elif comm is None:
+            # ONE RCCL all-reduce (8 MB) per step, in the step's own order, then the guess numbers from the summed
+            # positions (a summed position is > 0 exactly when some shard counted a sample).  Not beside the next
+            # step's sampling (--overlap-comm does that): on one GPU every kernel put beside the sampler on another
+            # stream cost more than it hid (the 8 MB copy alone: 1.52 against 1.33 ms a step).
+            if args.rehearse_on_one_gpu:
+                torch.cuda.synchronize()                    # (gloo on a shared GPU: see below)
+            mcd.combine_positions(q_pos[slot])
+            marks[9].record()
+            device_guess_numbers(q_pos[slot], None, True, out=g_rank[slot], workspace=ws_gn, exact=g_exact[slot])
             marks[8].record()
             ready = marks[8]
         else:
@@ -278,7 +293,7 @@ def main():
             ev["score"].append((marks[3], marks[4]))
             ev["order"].append((marks[4], marks[6]))
             ev["query"].append((marks[5], marks[7]))
-            ev["guess_numbers"].append((marks[7] if comm is None else marks[9], marks[8]))
+            ev["guess_numbers"].append((marks[7] if world == 1 else marks[9], marks[8]))
             ev["d2h"].append((marks[10], marks[11]))
 
     def fence():

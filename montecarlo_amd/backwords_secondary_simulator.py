@@ -29,3 +29,14 @@ class BackWordsSecondaryMonteCarlo(BackWordsMonteCarlo):
             return
         table = expand_2d(freq2prob(counts, config['threshold']))
         self._adopt(table, words, config['start_chr'], config['end_chr'], max_iter)
+
+
+def wrapper(argv=None):
+    """The reference's command line (backwords_secondary_simulator.py:28-60); the flags live in montecarlo_amd/_cli.py."""
+    from . import _cli
+    return _cli.backwords_secondary_simulator(argv)
+
+
+if __name__ == '__main__':
+    from . import _cli
+    _cli.run(wrapper)

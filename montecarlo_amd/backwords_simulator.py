@@ -45,3 +45,14 @@ class BackWordsMonteCarlo(NWordsMonteCarlo):
         self.max_iter = max_iter
         # the history starts as list(default_start): the characters of the start string
         self._attach(nv.KIND_BACKOFF, order=0, start_units=tuple(start_chr), end_chr=end_chr, min_len=self.min_len)
+
+
+def wrapper(argv=None):
+    """The reference's command line (backwords_simulator.py:52-99); the flags live in montecarlo_amd/_cli.py."""
+    from . import _cli
+    return _cli.backwords_simulator(argv)
+
+
+if __name__ == '__main__':
+    from . import _cli
+    _cli.run(wrapper)

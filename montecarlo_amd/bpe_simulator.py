@@ -125,3 +125,20 @@ class BpePcfgSim(MonteCarlo):
                 lut[c] = char_class(chr(c))
         table = np.array([lut[c] for c in uniq.tolist()], dtype=np.uint8)
         return table[np.searchsorted(uniq, cps)] if len(cps) else np.zeros(0, dtype=np.uint8)
+
+
+def wrapper(model_path: str, testing_set, save2, size: int = 1000000):
+    """bpe_simulator.py:160-172: the driver flow with a re-sort and the +1."""
+    from . import _cli
+    _cli.driver_flow(BpePcfgSim(model_path=model_path), testing_set, save2, size, need_resort=True, add1=True)
+
+
+def main(argv=None):
+    """The reference's command line (bpe_simulator.py:175-199)."""
+    from . import _cli
+    return _cli.bpe_simulator(argv)
+
+
+if __name__ == '__main__':
+    from . import _cli
+    _cli.run(main)

@@ -49,3 +49,14 @@ class NWordsMonteCarlo(TableBacked, MonteCarlo):
     @nwords.setter
     def nwords(self, table):
         self.__dict__["_nwords"] = table
+
+
+def wrapper(argv=None):
+    """The reference's command line (nwords_simulator.py:119-149); the flags live in montecarlo_amd/_cli.py."""
+    from . import _cli
+    return _cli.nwords_simulator(argv)
+
+
+if __name__ == '__main__':
+    from . import _cli
+    _cli.run(wrapper)

@@ -55,3 +55,14 @@ class NWords2MonteCarlo(TableBacked, MonteCarlo):
 
     def _score_unique_device(self, lines):
         return self.score_batch(None)
+
+
+def main(argv=None):
+    """The reference's command line (nwords_simulator_v2.py:98-114); the flags live in montecarlo_amd/_cli.py."""
+    from . import _cli
+    return _cli.nwords_simulator_v2(argv)
+
+
+if __name__ == '__main__':
+    from . import _cli
+    _cli.run(main)

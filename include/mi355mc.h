@@ -393,6 +393,11 @@ int mc_rank_build(const double *keys_in, uint64_t n, uint64_t n_global, double *
 int mc_rank_check(const void *workspace, uint64_t n, void *stream, uint64_t info[8]);
 /* Test hook: while on, every mc_rank_build takes its device-side failure path (tables "overflow" at once). */
 void mc_rank_debug_fail(int on);
+/* Test / measurement hook: how mc_rank_build looks for the values that repeat often.  0 (default): by size --
+ * from 2^26 keys on a 2^19-key sample is counted and up to 3072 values are taken out of the sort, below that a
+ * 16384-key sample and up to 1024 values; 1: the large search wherever the workspace holds its tables (2^22 keys
+ * and more); 2: never.  The result is the same sorted array either way. */
+void mc_rank_debug_search(int mode);
 
 /* mc_rank_build for callers that cannot allocate device memory (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE: it is the same

@@ -163,6 +163,7 @@ u32 scan_blocks(u64 n) {
 }
 
 std::atomic<int> g_debug_fail{0};
+std::atomic<int> g_search_mode{0};  // 0 = by size, 1 = the large search for heavy values wherever it is laid out, 2 = never
 
 }  // namespace
 
@@ -171,6 +172,16 @@ extern "C" size_t mc_rank_workspace_bytes(uint64_t n) {
 }
 
 extern "C" void mc_rank_debug_fail(int on) { g_debug_fail.store(on ? 1 : 0); }
+
+extern "C" void mc_rank_debug_search(int mode) { g_search_mode.store(mode == 1 || mode == 2 ? mode : 0); }
+
+namespace {
+int sort_flags() {
+    const int mode = g_search_mode.load();
+    return (g_debug_fail.load() ? MC_SORT_DEBUG_FAIL : 0) |
+           (mode == 1 ? MC_SORT_LARGE_SEARCH : mode == 2 ? MC_SORT_SMALL_SEARCH : 0);
+}
+}  // namespace
 
 extern "C" int mc_rank_build(const double *keys_in, uint64_t n, uint64_t n_global, double *keys_sorted,
                              double *positions, void *workspace, size_t workspace_bytes, void *stream) {
@@ -194,7 +205,7 @@ extern "C" int mc_rank_build(const double *keys_in, uint64_t n, uint64_t n_globa
     uint32_t *err = nullptr;
     {
         int rc = mc_sort_keys((const uint64_t *)keys_in, n, (uint64_t *)keys_sorted, workspace, sort_bytes, &err,
-                              g_debug_fail.load() ? MC_SORT_DEBUG_FAIL : 0, s);
+                              sort_flags(), s);
         if (rc != MC_OK) return rc;
     }
     // positions

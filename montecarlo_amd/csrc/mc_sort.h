@@ -14,7 +14,9 @@ size_t mc_sort_workspace_bytes(uint64_t n);
 // and `out` is not sorted (the caller poisons what it derives from it).  flags: MC_SORT_DEBUG_FAIL forces that
 // failure path (tests); MC_SORT_FEW_REPEATS says no value is expected to repeat often (the search for heavy
 // values and the kernel that writes their runs are not launched; any input is still sorted correctly).
-enum { MC_SORT_DEBUG_FAIL = 1, MC_SORT_FEW_REPEATS = 2 };
+// Inputs of 2^26 keys and more look for their heavy values in a larger sample (up to 3072 instead of 1024 values);
+// MC_SORT_LARGE_SEARCH asks for that from 2^22 keys on, MC_SORT_SMALL_SEARCH never (tests and measurements).
+enum { MC_SORT_DEBUG_FAIL = 1, MC_SORT_FEW_REPEATS = 2, MC_SORT_LARGE_SEARCH = 4, MC_SORT_SMALL_SEARCH = 8 };
 int mc_sort_keys(const uint64_t *in, uint64_t n, uint64_t *out, void *workspace, size_t workspace_bytes,
                  uint32_t **err_word_out, int flags, hipStream_t stream);
 

@@ -56,6 +56,13 @@ constexpr int NWAVE = WG / 64;
 constexpr int STRIP_SLOTS = 512;   // k_strip workgroups a GPU holds at once (104 VGPRs: two a CU): regions are sized for ONE round of them
 constexpr int SNIFF_S = 16384, SNIFF_SLOTS = 16384, SNIFF_MIN = 5, SNIFF_THREADS = 1024, SNIFF_PROBES = 8;
 constexpr int H_MAX = 1024, HSET = 2048;
+// Large inputs (n >= BIG_N) look for more heavy values in a larger sample, counted over several workgroups in a
+// table in the workspace: at 1.25e9 keys the 16384-key sample finds ~450 values (60-80 % of the keys) and the tail
+// then pays 12 B a key and level; 3072 values cover 82-96 %.
+constexpr int H_BIG = 3072, HSET_BIG = 6144;       // (6144 slots of 12 B: two k_strip workgroups still share a CU)
+constexpr int BIG_S = 1 << 19, BIG_WGS = BIG_S / SNIFF_S, BIG_MIN = 6;
+constexpr u32 G_SLOTS = 1u << 20, G_PROBES = 64, CNT_BINS = 1024, NONE = 0xFFFFFFFFu;
+constexpr u64 BIG_N = 1ull << 26, BIG_LAYOUT_N = 1ull << 22;
 constexpr int COPIES = 4;          // lane-sliced copies of LDS histograms: lanes l, l+4, ... share one
 constexpr int MAX_LEVELS = 8;      // 64 bits / 8
 constexpr int BINS = 4096;         // buckets of a finish tile
@@ -76,6 +83,8 @@ struct Ctl {
     u32 nft;
     u32 segs_total;
     u32 deep_top;  // segments handed to k_deep's workgroups by their own plans (entries of the deep arena)
+    u32 n_picked;  // large inputs: sample values at or above the bar (before they are sorted)
+    u32 bar;       // ... and the bar
 };
 
 struct Seg {
@@ -109,6 +118,15 @@ struct Ws {
     u64 *A, *B, *C;
     u32 n, region, regions;
     u32 cap_seg, cap_tile, cap_ft;
+    // large inputs only (null otherwise)
+    u64 *gk;         // [G_SLOTS] sample values (EMPTY = free)
+    u32 *gc;         // [G_SLOTS] their counts in the sample
+    u32 *ghist;      // [CNT_BINS] values per count (counts capped at CNT_BINS - 1)
+    u64 *glist;      // [H_BIG] the values at or above the bar, unsorted
+    u32 *glcnt;      // [H_BIG] their counts in the sample
+    u64 *hkg;        // [HSET_BIG + 1] k_strip's hash set of the heavy values, built once
+    u32 *hig;        // [HSET_BIG + 1] slot -> index of the heavy value (NONE = free)
+    u32 *hpg;        // [H_BIG + 1] copies of the heavy values below index i
 };
 
 __device__ __forceinline__ u32 hset_hash(u64 k) { return (u32)((k * 0x9E3779B97F4A7C15ull) >> 40); }
@@ -176,31 +194,21 @@ __device__ __forceinline__ u32 sniff_mix(u64 k) {
     return x * 0x85EBCA6Bu;
 }
 
-__global__ void __launch_bounds__(SNIFF_THREADS) k_sniff(Ws w) {
-    constexpr int PER = SNIFF_S / SNIFF_THREADS;
-    static_assert(SNIFF_SLOTS == 16384, "slot = top 14 bits of the mix");
-    __shared__ u32 tag[SNIFF_SLOTS];          // 0 = empty
-    __shared__ u32 tc[SNIFF_SLOTS / 2];       // two 16-bit counts per word
-    __shared__ u32 claim[SNIFF_SLOTS / 32];
-    __shared__ u64 list[H_MAX];
-    __shared__ u32 nlist;
-    const u32 n = w.n;
-    const int tid = threadIdx.x;
-    if (n < (u32)SNIFF_S * 4) return;  // small inputs: no heavy values (n_heavy stays 0)
-    for (int i = tid; i < SNIFF_SLOTS; i += SNIFF_THREADS) tag[i] = 0;
-    for (int i = tid; i < SNIFF_SLOTS / 2; i += SNIFF_THREADS) tc[i] = 0;
-    for (int i = tid; i < SNIFF_SLOTS / 32; i += SNIFF_THREADS) claim[i] = 0;
-    __syncthreads();
+constexpr int SNIFF_BLOCK = 16;  // consecutive keys per sampled block
+
+// One workgroup's SNIFF_S sample keys (block `block0 + i` of SNIFF_BLOCK keys starts at (block0 + i) * bstride),
+// counted per slot of the LDS tag table; slot[q] = the slot of key q, or 0xFFFFFFFF when it found no place.
+template <int PER>
+__device__ __forceinline__ void sniff_sample(const u64 *in, u64 bstride, u32 block0, u32 *tag, u32 *tc, u64 (&k)[PER],
+                                             u32 (&slot)[PER]) {
     // (blocks of consecutive keys: 1024 pages touched; every key at its own stride was one address translation
     // per key for this one compute unit, most of the kernel's time)
-    constexpr int BLOCK = 16, BLOCKS = SNIFF_S / BLOCK;
-    const u64 bstride = n / BLOCKS;
-    u64 k[PER];
-    u32 slot[PER];
+    constexpr int BLOCK = SNIFF_BLOCK;
+    const int tid = threadIdx.x;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         const u32 block = (u32)((q * SNIFF_THREADS + tid) / BLOCK);
-        k[q] = w.in[(u64)block * bstride + (u32)(tid % BLOCK)];
+        k[q] = in[(u64)(block0 + block) * bstride + (u32)(tid % BLOCK)];
     }
     // every key tries its home slot first, all PER attempts in flight together (one after the other they were PER
     // dependent LDS round trips); only a key that finds another value there walks on
@@ -229,6 +237,26 @@ __global__ void __launch_bounds__(SNIFF_THREADS) k_sniff(Ws w) {
 #pragma unroll
     for (int q = 0; q < PER; ++q)
         if (slot[q] != 0xFFFFFFFFu) atomicAdd(&tc[slot[q] >> 1], 1u << (16 * (slot[q] & 1u)));
+}
+
+__global__ void __launch_bounds__(SNIFF_THREADS) k_sniff(Ws w) {
+    constexpr int PER = SNIFF_S / SNIFF_THREADS;
+    static_assert(SNIFF_SLOTS == 16384, "slot = top 14 bits of the mix");
+    __shared__ u32 tag[SNIFF_SLOTS];          // 0 = empty
+    __shared__ u32 tc[SNIFF_SLOTS / 2];       // two 16-bit counts per word
+    __shared__ u32 claim[SNIFF_SLOTS / 32];
+    __shared__ u64 list[H_MAX];
+    __shared__ u32 nlist;
+    const u32 n = w.n;
+    const int tid = threadIdx.x;
+    if (n < (u32)SNIFF_S * 4) return;  // small inputs: no heavy values (n_heavy stays 0)
+    for (int i = tid; i < SNIFF_SLOTS; i += SNIFF_THREADS) tag[i] = 0;
+    for (int i = tid; i < SNIFF_SLOTS / 2; i += SNIFF_THREADS) tc[i] = 0;
+    for (int i = tid; i < SNIFF_SLOTS / 32; i += SNIFF_THREADS) claim[i] = 0;
+    __syncthreads();
+    u64 k[PER];
+    u32 slot[PER];
+    sniff_sample<PER>(w.in, n / (SNIFF_S / SNIFF_BLOCK), 0u, tag, tc, k, slot);
     u32 bar = SNIFF_MIN;
     for (;;) {  // (uniform: every thread sees the same nlist)
         __syncthreads();
@@ -296,13 +324,20 @@ __device__ __forceinline__ u32 strip_hash(u64 k) {
     x ^= x >> 15;
     return (x * 0x85EBCA6Bu) >> 21;  // 11 bits = HSET slots
 }
+__device__ __forceinline__ u32 strip_hash_big(u64 k) {  // HSET_BIG slots (not a power of two)
+    const u32 lo = (u32)k, hi = (u32)(k >> 32);
+    u32 x = lo ^ (hi * 0x9E3779B1u);
+    x ^= x >> 15;
+    return __umulhi(x * 0x85EBCA6Bu, (u32)HSET_BIG);
+}
 
 // One tile of k_strip.  FULL: every lane holds ITEMS keys (no validity tests at all: they were a branch per load
 // and per key).  Heavy test without branches: the key's home slot and the next one are read together; only a key
 // that meets two other values there walks on (rare: the table is at most half full, 14 % on the headline model).
-template <bool FULL>
+template <bool FULL, bool BIG>
 __device__ __forceinline__ void strip_tile(const u64 (&k)[ITEMS], u32 c0, u32 rn, u64 lo, u32 H, const u64 *hk,
                                            u32 *hs, u32 *h48, u32 *h56, u32 *roff, u64 *B, u64 &o, u64 &no) {
+    constexpr u32 SLOTS = BIG ? (u32)HSET_BIG : (u32)HSET;
     const int tid = threadIdx.x, lane = tid & 63;
     const u32 cp = (u32)(lane & (COPIES - 1)) * 256u;
     const u64 lt = (1ull << lane) - 1ull;
@@ -313,23 +348,24 @@ __device__ __forceinline__ void strip_tile(const u64 (&k)[ITEMS], u32 c0, u32 rn
         u64 a[ITEMS], b[ITEMS];
 #pragma unroll
         for (int q = 0; q < ITEMS; ++q) {
-            s[q] = strip_hash(k[q]);
+            s[q] = BIG ? strip_hash_big(k[q]) : strip_hash(k[q]);
             a[q] = hk[s[q]];
-            b[q] = hk[s[q] + 1];  // (slot HSET is a spare that stays empty)
+            b[q] = hk[s[q] + 1];  // (slot HSET is a spare that stays empty; BIG: the last slot's neighbour)
         }
 #pragma unroll
         for (int q = 0; q < ITEMS; ++q) {
             const bool valid = FULL || c0 + q * WG + tid < rn;
             const bool real = valid && k[q] != EMPTY;  // (a key equal to the empty marker is never heavy)
             const bool hit_a = real && a[q] == k[q];
-            const bool hit_b = real && !hit_a && a[q] != EMPTY && b[q] == k[q];
+            // (BIG: a value lies in its home slot or the next one, or it is not in the set -- k_sniff_sort)
+            const bool hit_b = real && !hit_a && (BIG || a[q] != EMPTY) && b[q] == k[q];
             // (a miss is decided when a slot is empty; the table wraps, so the spare slot decides nothing)
-            bool walk = real && !hit_a && !hit_b && a[q] != EMPTY && (b[q] != EMPTY || s[q] + 1 == (u32)HSET);
+            bool walk = !BIG && real && !hit_a && !hit_b && a[q] != EMPTY && (b[q] != EMPTY || s[q] + 1 == SLOTS);
             bool heavy = hit_a || hit_b;
             u32 slot = s[q] + (hit_b ? 1u : 0u);
-            if (__ballot(walk)) {  // (rare)
+            if (!BIG && __ballot(walk)) {  // (rare)
                 if (walk) {
-                    u32 t = s[q] + 1 == (u32)HSET ? 0u : ((s[q] + 2) & (HSET - 1));
+                    u32 t = s[q] + 1 == SLOTS ? 0u : (s[q] + 2 == SLOTS ? 0u : s[q] + 2);
                     for (;;) {
                         const u64 v = hk[t];
                         if (v == k[q]) {
@@ -338,7 +374,7 @@ __device__ __forceinline__ void strip_tile(const u64 (&k)[ITEMS], u32 c0, u32 rn
                             break;
                         }
                         if (v == EMPTY) break;
-                        t = (t + 1) & (HSET - 1);
+                        t = t + 1 == SLOTS ? 0u : t + 1;
                     }
                 }
             }
@@ -391,35 +427,40 @@ __device__ __forceinline__ void strip_tile(const u64 (&k)[ITEMS], u32 c0, u32 rn
     }
 }
 
+// BIG: the hash set was built once (k_sniff_sort) and is copied in; slot -> value index stays in memory.
+template <bool BIG>
 __global__ void __launch_bounds__(WG) k_strip(Ws w) {
     static_assert(HSET == 2048, "strip_hash yields 11 bits");
-    __shared__ u64 hk[HSET + 1];  // (+1: the pair read of the last slot)
-    __shared__ u32 hs[HSET];      // copies counted per slot
-    __shared__ u32 hi[HSET];      // slot -> index of the heavy value
+    constexpr u32 SLOTS = BIG ? (u32)HSET_BIG : (u32)HSET;
+    __shared__ u64 hk[SLOTS + 1];         // (+1: the pair read of the last slot)
+    __shared__ u32 hs[SLOTS + 1];         // copies counted per slot
+    __shared__ u32 hi[BIG ? 1 : HSET];    // slot -> index of the heavy value
     __shared__ u32 h48[256 * COPIES], h56[256];
     __shared__ u32 roff;
     __shared__ u64 red[2 * NWAVE];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const u32 H = w.ctl->n_heavy;
     const u32 n = w.n;
-    for (int i = tid; i <= HSET; i += WG) hk[i] = EMPTY;
-    for (int i = tid; i < HSET; i += WG) hs[i] = 0;
+    for (u32 i = tid; i <= SLOTS; i += WG) hk[i] = BIG ? w.hkg[i] : EMPTY;
+    for (u32 i = tid; i <= SLOTS; i += WG) hs[i] = 0;
     for (int i = tid; i < 256 * COPIES; i += WG) h48[i] = 0;
     if (tid < 256) h56[tid] = 0;
     __syncthreads();
-    for (u32 i = tid; i < H; i += WG) {
-        const u64 v = w.heavy[i];
-        u32 s = strip_hash(v);
-        for (;;) {  // H <= HSET / 2 distinct values
-            const u64 old = atomicCAS(&hk[s], EMPTY, v);
-            if (old == EMPTY) {
-                hi[s] = i;
-                break;
+    if (!BIG) {
+        for (u32 i = tid; i < H; i += WG) {
+            const u64 v = w.heavy[i];
+            u32 s = strip_hash(v);
+            for (;;) {  // H <= HSET / 2 distinct values
+                const u64 old = atomicCAS(&hk[s], EMPTY, v);
+                if (old == EMPTY) {
+                    hi[s] = i;
+                    break;
+                }
+                s = (s + 1) & (HSET - 1);
             }
-            s = (s + 1) & (HSET - 1);
         }
+        __syncthreads();
     }
-    __syncthreads();
     u64 o = 0, no = 0;
     u32 tail_total = 0;  // (thread 0)
     for (u32 r = blockIdx.x; r < w.regions; r += gridDim.x) {
@@ -443,8 +484,8 @@ __global__ void __launch_bounds__(WG) k_strip(Ws w) {
                     nk[q] = w.in[lo + (j < rn ? j : rn - 1)];
                 }
             }
-            if (c0 + TILE <= rn) strip_tile<true>(k, c0, rn, lo, H, hk, hs, h48, h56, &roff, w.B, o, no);
-            else strip_tile<false>(k, c0, rn, lo, H, hk, hs, h48, h56, &roff, w.B, o, no);
+            if (c0 + TILE <= rn) strip_tile<true, BIG>(k, c0, rn, lo, H, hk, hs, h48, h56, &roff, w.B, o, no);
+            else strip_tile<false, BIG>(k, c0, rn, lo, H, hk, hs, h48, h56, &roff, w.B, o, no);
         }
         __syncthreads();
         if (tid == 0) {
@@ -484,13 +525,221 @@ __global__ void __launch_bounds__(WG) k_strip(Ws w) {
     // (slot order) are one memory-side request each and queue on its few lines (measured: 120 us for 266 values
     // x 611 workgroups)
     __syncthreads();
-    u32 *hc = h48;  // (256 * COPIES = H_MAX words, free again)
     static_assert(256 * COPIES >= H_MAX, "h48 is reused for the per-value counts");
-    for (u32 i = tid; i < (u32)HSET; i += WG)
-        if (hk[i] != EMPTY) hc[hi[i]] = hs[i];
+    static_assert((HSET_BIG + 1) * 2 >= H_BIG, "the hash set's own memory is reused for the per-value counts");
+    u32 *hc = BIG ? (u32 *)hk : h48;  // (free again: the keys are all looked up; h48 holds H_MAX words)
+    if (BIG) {
+        for (u32 i = tid; i < H; i += WG) hc[i] = 0;
+        __syncthreads();
+        for (u32 i = tid; i <= SLOTS; i += WG) {
+            const u32 c = hs[i], idx = c ? w.hig[i] : NONE;
+            if (idx < H) hc[idx] = c;
+        }
+    } else {
+        for (u32 i = tid; i < SLOTS; i += WG)
+            if (hk[i] != EMPTY) hc[hi[i]] = hs[i];
+    }
     __syncthreads();
     for (u32 i = tid; i < H; i += WG)
         if (hc[i]) atomicAdd(&w.hcnt[i], hc[i]);
+}
+
+// ---- heavy values of a large input ------------------------------------------------------------------------
+// BIG_S sample keys instead of 16384: BIG_WGS workgroups count SNIFF_S keys each as k_sniff does and add every
+// slot's (value, count) to one table in the workspace; a histogram of the counts gives the bar that leaves at most
+// H_BIG values; those are listed, sorted, and hashed ONCE into the set every k_strip workgroup copies.  Any list
+// of distinct values is a correct list (a value's copies are counted exactly by k_strip, whatever the sample
+// said): a tag shared by two values or a full probe window only costs a better choice.
+__device__ __forceinline__ u32 g_hash(u64 k) { return (u32)((k * 0x9E3779B97F4A7C15ull) >> 44); }  // 20 bits
+static_assert(G_SLOTS == 1u << 20, "g_hash yields 20 bits");
+
+__global__ void __launch_bounds__(SNIFF_THREADS) k_sniff_count(Ws w) {
+    constexpr int PER = SNIFF_S / SNIFF_THREADS;
+    __shared__ u32 tag[SNIFF_SLOTS];
+    __shared__ u32 tc[SNIFF_SLOTS / 2];
+    __shared__ u32 claim[SNIFF_SLOTS / 32];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < SNIFF_SLOTS; i += SNIFF_THREADS) tag[i] = 0;
+    for (int i = tid; i < SNIFF_SLOTS / 2; i += SNIFF_THREADS) tc[i] = 0;
+    for (int i = tid; i < SNIFF_SLOTS / 32; i += SNIFF_THREADS) claim[i] = 0;
+    __syncthreads();
+    constexpr u32 BLOCKS = SNIFF_S / SNIFF_BLOCK;  // per workgroup
+    u64 k[PER];
+    u32 slot[PER];
+    // (the host launches this for n >= BIG_LAYOUT_N only: a block's stride is far above its 16 keys)
+    sniff_sample<PER>(w.in, w.n / (BLOCKS * gridDim.x), blockIdx.x * BLOCKS, tag, tc, k, slot);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const u32 s = slot[q];
+        if (s == 0xFFFFFFFFu || k[q] == EMPTY) continue;  // (a key equal to the empty marker is never heavy)
+        const u32 bit = 1u << (s & 31u);
+        if (atomicOr(&claim[s >> 5], bit) & bit) continue;  // one key speaks for its slot
+        const u32 c = (tc[s >> 1] >> (16 * (s & 1u))) & 0xFFFFu;
+        u32 g = g_hash(k[q]);
+        for (u32 probe = 0; probe < G_PROBES; ++probe) {
+            const u64 old = atomicCAS(&w.gk[g], EMPTY, k[q]);
+            if (old == EMPTY || old == k[q]) {
+                atomicAdd(&w.gc[g], c);
+                break;
+            }
+            g = (g + 1) & (G_SLOTS - 1);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_sniff_hist(Ws w) {
+    __shared__ u32 lh[CNT_BINS];
+    static_assert(CNT_BINS == 1024, "one bin per thread");
+    const u32 tid = threadIdx.x;
+    lh[tid] = 0;
+    __syncthreads();
+    for (u32 i = blockIdx.x * 1024u + tid; i < G_SLOTS; i += gridDim.x * 1024u) {
+        const u32 c = w.gc[i];
+        if (c >= (u32)BIG_MIN) atomicAdd(&lh[c < CNT_BINS ? c : CNT_BINS - 1], 1u);
+    }
+    __syncthreads();
+    if (lh[tid]) atomicAdd(&w.ghist[tid], lh[tid]);
+}
+
+__global__ void __launch_bounds__(1024) k_sniff_pick(Ws w) {
+    __shared__ u32 wt[16];
+    __shared__ u32 bar_s;
+    const u32 tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    // values with a count of at least c, for c = CNT_BINS - 1 - tid: an inclusive scan from the top
+    const u32 c = CNT_BINS - 1 - tid;
+    u32 inc = w.ghist[c];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 t = __shfl_up(inc, o);
+        if (lane >= (u32)o) inc += t;
+    }
+    if (lane == 63) wt[wid] = inc;
+    if (tid == 0) bar_s = CNT_BINS;  // (no count qualifies: nothing is picked)
+    __syncthreads();
+    for (u32 i = 0; i < wid; ++i) inc += wt[i];
+    // the lowest bar that leaves at most H_BIG values (counts are capped at CNT_BINS - 1, where fewer than
+    // BIG_S / (CNT_BINS - 1) < H_BIG values can be: the bar never needs to go beyond the cap)
+    if (c >= (u32)BIG_MIN && inc <= (u32)H_BIG) atomicMin(&bar_s, c);
+    __syncthreads();
+    const u32 bar = bar_s;
+    for (u32 i = blockIdx.x * 1024u + tid; i < G_SLOTS; i += gridDim.x * 1024u) {
+        const u32 v = w.gc[i];
+        if ((v < CNT_BINS ? v : CNT_BINS - 1) >= bar) {
+            const u32 p = atomicAdd(&w.ctl->n_picked, 1u);
+            if (p < (u32)H_BIG) {
+                w.glist[p] = w.gk[i];
+                w.glcnt[p] = v;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) w.ctl->bar = bar;
+}
+
+// One workgroup: k_strip's hash set of the picked values, then the values in ascending order (bitonic network in
+// LDS).  The set is built so that a lookup is two reads and never a walk: a value lies in its home slot or the
+// next one; a value that finds both taken is left out of the list (it stays in the tail; at half load 9 % of
+// the values, which go in by descending count so that the commonest are placed while the table is empty).
+// (With open-ended probing every wave of k_strip walked for its unluckiest lane: 8.3 ms instead of 4.4 at 1.25e9.)
+__global__ void __launch_bounds__(1024) k_sniff_sort(Ws w) {
+    constexpr u32 M = 4096;
+    static_assert(H_BIG <= M, "the network sorts M keys");
+    __shared__ u64 a[M];
+    __shared__ u64 hk[HSET_BIG + 1];
+    __shared__ u32 hi[HSET_BIG + 1];
+    __shared__ u32 kept;
+    const u32 tid = threadIdx.x;
+    const u32 picked = w.ctl->n_picked, bar = w.ctl->bar;
+    const u32 P = picked < (u32)H_BIG ? picked : (u32)H_BIG;
+    constexpr int PT = M / 1024;
+    u32 cnt[PT];
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+        const u32 i = q * 1024u + tid;
+        a[i] = i < P ? w.glist[i] : EMPTY;  // (no picked value is EMPTY)
+        cnt[q] = i < P ? w.glcnt[i] : 0u;
+    }
+    for (u32 i = tid; i <= (u32)HSET_BIG; i += 1024u) {
+        hk[i] = EMPTY;
+        hi[i] = NONE;
+    }
+    if (tid == 0) kept = 0;
+    __syncthreads();
+    for (int round = 0; round < 4; ++round) {  // counts of 64, 16, 4 bars and more, then the rest
+        const u64 from = round < 3 ? (u64)bar << (6 - 2 * round) : 0ull;
+        const u64 below = round ? (u64)bar << (8 - 2 * round) : ~0ull;
+#pragma unroll
+        for (int q = 0; q < PT; ++q) {
+            const u32 i = q * 1024u + tid;
+            if (i < P && cnt[q] >= from && cnt[q] < below) {
+                const u64 v = a[i];
+                const u32 s = strip_hash_big(v);
+                if (atomicCAS(&hk[s], EMPTY, v) != EMPTY && atomicCAS(&hk[s + 1], EMPTY, v) != EMPTY) a[i] = EMPTY;
+            }
+        }
+        __syncthreads();
+    }
+    for (u32 k2 = 2; k2 <= M; k2 <<= 1) {
+        for (u32 j = k2 >> 1; j > 0; j >>= 1) {
+            for (u32 t = tid; t < M / 2; t += 1024u) {
+                const u32 lo = ((t / j) * 2u * j) + (t % j), hi2 = lo + j;
+                const bool up = (lo & k2) == 0;
+                const u64 x = a[lo], y = a[hi2];
+                if ((x > y) == up) {
+                    a[lo] = y;
+                    a[hi2] = x;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (u32 i = tid; i < M; i += 1024u) {
+        const u64 v = a[i];
+        if (v == EMPTY) continue;
+        if (i + 1 == M || a[i + 1] == EMPTY) kept = i + 1;  // (one thread: the values are distinct)
+        w.heavy[i] = v;
+        const u32 s = strip_hash_big(v);
+        hi[hk[s] == v ? s : s + 1] = i;
+    }
+    __syncthreads();
+    for (u32 i = tid; i <= (u32)HSET_BIG; i += 1024u) {
+        w.hkg[i] = hk[i];
+        w.hig[i] = hi[i];
+    }
+    if (tid == 0) w.ctl->n_heavy = kept;
+}
+
+// hpg[i] = copies of the heavy values below index i (i <= H), for k_finish<BIG>
+__global__ void __launch_bounds__(1024) k_heavy_prefix(Ws w) {
+    constexpr int PT = H_BIG / 1024;
+    static_assert(PT * 1024 == H_BIG, "whole heavy values per thread");
+    __shared__ u32 wt[16];
+    const u32 tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    const u32 H = w.ctl->n_heavy;
+    u32 c[PT], s = 0;
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+        const u32 i = tid * PT + q;
+        c[q] = i < H ? w.hcnt[i] : 0u;
+        s += c[q];
+    }
+    u32 inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 t = __shfl_up(inc, o);
+        if (lane >= (u32)o) inc += t;
+    }
+    if (lane == 63) wt[wid] = inc;
+    __syncthreads();
+    u32 ex = inc - s;
+    for (u32 i = 0; i < wid; ++i) ex += wt[i];
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+        const u32 i = tid * PT + q;
+        if (i <= H) w.hpg[i] = ex;
+        ex += c[q];
+    }
+    if (tid == 1023 && H == (u32)H_BIG) w.hpg[H] = ex;
 }
 
 // ---- one MSD level --------------------------------------------------------------------------------------
@@ -1025,12 +1274,17 @@ __device__ __forceinline__ void wave_sort(u64 *a, u32 g, int lane) {
     }
 }
 
+// BIG (up to H_BIG heavy values): only the values themselves are held in LDS -- with their prefix sums and the gap
+// counters beside them one workgroup would have a CU to itself; the prefix sums are read from memory
+// (k_heavy_prefix), once per tile unless a heavy value lies inside the tile's range, and the gaps are counted there.
+template <bool BIG>
 __global__ void __launch_bounds__(WG, 4) k_finish(Ws w) {  // (4 waves per SIMD = two workgroups a CU: 128 VGPRs)
+    constexpr u32 HM = BIG ? (u32)H_BIG : (u32)H_MAX;
     __shared__ u64 stage[CAP];
     __shared__ u32 start[BINS + 1];
-    __shared__ u64 hv[H_MAX];
-    __shared__ u32 hp[H_MAX + 1];    // copies of the heavy values below index i
-    __shared__ u32 gapl[H_MAX + 1];
+    __shared__ u64 hv[HM];
+    __shared__ u32 hp[BIG ? 1 : H_MAX + 1];    // copies of the heavy values below index i
+    __shared__ u32 gapl[BIG ? 1 : H_MAX + 1];
     __shared__ u32 wtot[NWAVE];
     __shared__ u64 red[2 * NWAVE];
     __shared__ u32 large[2 * LARGE_CAP];
@@ -1056,7 +1310,9 @@ __global__ void __launch_bounds__(WG, 4) k_finish(Ws w) {  // (4 waves per SIMD 
     };
     request(blockIdx.x);
     // heavy values and the prefix sums of their copies
-    {
+    if (BIG) {
+        for (u32 i = tid; i < H; i += WG) hv[i] = w.heavy[i];
+    } else {
         u32 c[2];
         u32 s = 0;
 #pragma unroll
@@ -1091,20 +1347,25 @@ __global__ void __launch_bounds__(WG, 4) k_finish(Ws w) {  // (4 waves per SIMD 
         u64 *out = w.A + f.off;
         const u64 room = (u64)w.n - f.off;  // a final index is < n; checked at every store
         u32 idx_lo = 0, idx_hi = 0;         // heavy values below the tile's smallest / largest key
+        u32 hp_lo = 0;                      // BIG: copies of the heavy values below the tile's smallest key
+        auto copies_below = [&](u32 hidx) { return BIG ? (hidx == idx_lo ? hp_lo : w.hpg[hidx]) : hp[hidx]; };
+        auto count_gap = [&](u32 hidx, u32 c) {
+            if (BIG) atomicAdd(&w.gap[hidx], c); else atomicAdd(&gapl[hidx], c);
+        };
         // `pos` = the key's rank inside the tile; its place in A adds the copies of the heavy values below it
         auto emit = [&](u32 pos, u64 key) {
             const u32 hidx = idx_lo == idx_hi ? idx_lo : heavy_below(key, idx_lo, idx_hi);
-            const u64 at = (u64)pos + hp[hidx];
+            const u64 at = (u64)pos + copies_below(hidx);
             if (at < room) out[at] = key; else atomicOr(&w.ctl->err, ERR_RANGE);
-            if (idx_lo != idx_hi) atomicAdd(&gapl[hidx], 1u);
+            if (idx_lo != idx_hi) count_gap(hidx, 1u);
         };
         auto emit_run = [&](u32 pos, u64 key, u32 c, int ln, int step) {  // c copies of key from rank pos on
             const u32 hidx = idx_lo == idx_hi ? idx_lo : heavy_below(key, idx_lo, idx_hi);
-            const u64 at0 = (u64)pos + hp[hidx];
+            const u64 at0 = (u64)pos + copies_below(hidx);
             for (u32 i = ln; i < c; i += step) {
                 if (at0 + i < room) out[at0 + i] = key; else atomicOr(&w.ctl->err, ERR_RANGE);
             }
-            if (ln == 0 && idx_lo != idx_hi) atomicAdd(&gapl[hidx], c);
+            if (ln == 0 && idx_lo != idx_hi) count_gap(hidx, c);
         };
         if (tid == 0) {
             nlarge = 0;
@@ -1144,6 +1405,7 @@ __global__ void __launch_bounds__(WG, 4) k_finish(Ws w) {  // (4 waves per SIMD 
             if (r == 0) {
                 idx_lo = heavy_below(mn, 0, H);
                 idx_hi = heavy_below(mx, idx_lo, H);
+                if (BIG) hp_lo = w.hpg[idx_lo];
             }
             if (mn == mx) {  // one value: a run
                 emit_run(s0, mn, g0, tid, WG);
@@ -1292,28 +1554,37 @@ __global__ void __launch_bounds__(WG, 4) k_finish(Ws w) {  // (4 waves per SIMD 
             if (tid == 0) nlarge = 0;
         }
         // (no heavy value inside the tile's range: all its keys have the same number of heavy values below)
-        if (idx_lo == idx_hi && tid == 0) gapl[idx_lo] += m;
+        if (idx_lo == idx_hi && tid == 0 && m) {
+            if (BIG) atomicAdd(&w.gap[idx_lo], m); else gapl[idx_lo] += m;
+        }
         if (t + gridDim.x < nft) request(t + gridDim.x);
     }
+    if (BIG) return;
     __syncthreads();
     for (u32 i = tid; i <= H; i += WG)
         if (gapl[i]) atomicAdd(&w.gap[i], gapl[i]);
 }
 
 // ---- the runs of the heavy values -----------------------------------------------------------------------
+template <bool BIG>
 __global__ void __launch_bounds__(256) k_fill(Ws w) {
     constexpr int CHUNK = 4096;
-    __shared__ u64 hv[H_MAX];
-    __shared__ u32 hp[H_MAX + 1];    // copies of heavy values below index i
-    __shared__ u32 st[H_MAX];        // final index of the first copy of heavy value i
+    constexpr u32 HM = BIG ? (u32)H_BIG : (u32)H_MAX;
+    constexpr int PT = HM / 256;     // heavy values per thread
+    static_assert(PT * 256 == HM, "whole heavy values per thread");
+    __shared__ u64 hv[HM];
+    __shared__ u32 hp[HM + 1];       // copies of heavy values below index i
+    __shared__ u32 st[HM];           // final index of the first copy of heavy value i
     const int tid = threadIdx.x;
     const u32 H = w.ctl->n_heavy;
     if (H == 0 || w.ctl->err) return;
     // prefix sums over the heavy values (parallel: a serial walk of LDS by one lane costs ~100 cycles a step)
     __shared__ u32 wtot[4];
-    auto scan4 = [&](u32 a0, u32 a1, u32 a2, u32 a3, u32 &total) {  // this thread's four consecutive entries
+    auto scan_own = [&](const u32 (&a)[PT], u32 &total) {  // this thread's PT consecutive entries
         const int lane = tid & 63, wid = tid >> 6;
-        const u32 s = a0 + a1 + a2 + a3;
+        u32 s = 0;
+#pragma unroll
+        for (int q = 0; q < PT; ++q) s += a[q];
         u32 inc = s;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -1331,34 +1602,33 @@ __global__ void __launch_bounds__(256) k_fill(Ws w) {
         total = tot;
         return off + inc - s;
     };
-    static_assert(H_MAX == 4 * 256, "four heavy values per thread");
-    u32 c[4], total;
+    u32 c[PT], total;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const u32 i = tid * 4 + q;
+    for (int q = 0; q < PT; ++q) {
+        const u32 i = tid * PT + q;
         c[q] = i < H ? w.hcnt[i] : 0u;
         if (i < H) hv[i] = w.heavy[i];
     }
-    u32 ex = scan4(c[0], c[1], c[2], c[3], total);
+    u32 ex = scan_own(c, total);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const u32 i = tid * 4 + q;
+    for (int q = 0; q < PT; ++q) {
+        const u32 i = tid * PT + q;
         if (i <= H) hp[i] = ex;
         ex += c[q];
     }
     if (tid == 0) hp[H] = total;
     if ((u64)blockIdx.x * CHUNK >= total) return;  // (uniform)
-    u32 g[4], gtot;
+    u32 g[PT], gtot;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const u32 i = tid * 4 + q;
+    for (int q = 0; q < PT; ++q) {
+        const u32 i = tid * PT + q;
         g[q] = i < H ? w.gap[i] : 0u;
     }
-    u32 gex = scan4(g[0], g[1], g[2], g[3], gtot);
+    u32 gex = scan_own(g, gtot);
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const u32 i = tid * 4 + q;
+    for (int q = 0; q < PT; ++q) {
+        const u32 i = tid * PT + q;
         gex += g[q];  // tail keys with at most i heavy values below them ARE below heavy value i
         if (i < H) st[i] = hp[i] + gex;
     }
@@ -1400,6 +1670,8 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Layout {
     size_t B, C, ctl, heavy, hcnt, gap, root, rcnt, segs[2], rows[2], tiles[2], ft, end;
+    size_t gk, gc, ghist, glist, glcnt, hkg, hig, hpg;  // large inputs (gk = 0: not laid out)
+    size_t gzero_bytes;                          // gc and ghist, cleared together
     u32 region, regions, cap_seg, cap_tile, cap_ft;
     size_t clear_from, clear_bytes;
 };
@@ -1422,9 +1694,11 @@ Layout layout_for(u64 n) {
     L.C = p; p += align256(n * sizeof(u64));
     L.clear_from = p;
     L.ctl = p; p += align256(sizeof(Ctl));
-    L.heavy = p; p += align256(H_MAX * sizeof(u64));
-    L.hcnt = p; p += align256(H_MAX * sizeof(u32));
-    L.gap = p; p += align256((H_MAX + 1) * sizeof(u32));
+    const bool big = n >= BIG_LAYOUT_N;
+    const size_t hm = big ? H_BIG : H_MAX;
+    L.heavy = p; p += align256(hm * sizeof(u64));
+    L.hcnt = p; p += align256(hm * sizeof(u32));
+    L.gap = p; p += align256((hm + 1) * sizeof(u32));
     L.root = p; p += align256(2 * sizeof(HistRow));
     L.clear_bytes = p - L.clear_from;
     L.rcnt = p; p += align256((size_t)L.regions * sizeof(u32));
@@ -1434,6 +1708,19 @@ Layout layout_for(u64 n) {
         L.tiles[i] = p; p += align256((size_t)L.cap_tile * sizeof(TileRef));
     }
     L.ft = p; p += align256((size_t)L.cap_ft * sizeof(FTile));
+    L.gk = L.gc = L.ghist = L.glist = L.glcnt = L.hkg = L.hig = L.hpg = 0;
+    L.gzero_bytes = 0;
+    if (big) {
+        L.gk = p; p += align256((size_t)G_SLOTS * sizeof(u64));
+        L.gc = p; p += align256((size_t)G_SLOTS * sizeof(u32));
+        L.ghist = p; p += align256((size_t)CNT_BINS * sizeof(u32));
+        L.gzero_bytes = p - L.gc;
+        L.glist = p; p += align256((size_t)H_BIG * sizeof(u64));
+        L.glcnt = p; p += align256((size_t)H_BIG * sizeof(u32));
+        L.hkg = p; p += align256((size_t)(HSET_BIG + 1) * sizeof(u64));
+        L.hig = p; p += align256((size_t)(HSET_BIG + 1) * sizeof(u32));
+        L.hpg = p; p += align256((size_t)(H_BIG + 1) * sizeof(u32));
+    }
     L.end = p;
     return L;
 }
@@ -1446,6 +1733,9 @@ int mc_sort_keys(const uint64_t *in, uint64_t n, uint64_t *out, void *workspace,
                  uint32_t **err_word_out, int flags, hipStream_t s) {
     const bool debug_fail = (flags & MC_SORT_DEBUG_FAIL) != 0, few_repeats = (flags & MC_SORT_FEW_REPEATS) != 0;
     const Layout L = layout_for(n);
+    // the larger search for heavy values: from BIG_N keys on (below it costs more than it saves), or on demand
+    const bool big = !few_repeats && L.gk != 0 && !(flags & MC_SORT_SMALL_SEARCH) &&
+                     (n >= BIG_N || (flags & MC_SORT_LARGE_SEARCH) != 0);
     if (workspace_bytes < L.end) {
         mc_set_error("mc_sort_keys: workspace of %zu bytes, need %zu", workspace_bytes, L.end);
         return MC_ERR_WORKSPACE;
@@ -1474,13 +1764,32 @@ int mc_sort_keys(const uint64_t *in, uint64_t n, uint64_t *out, void *workspace,
     w.cap_seg = L.cap_seg;
     w.cap_tile = L.cap_tile;
     w.cap_ft = L.cap_ft;
+    w.gk = big ? (u64 *)(base + L.gk) : nullptr;
+    w.gc = big ? (u32 *)(base + L.gc) : nullptr;
+    w.ghist = big ? (u32 *)(base + L.ghist) : nullptr;
+    w.glist = big ? (u64 *)(base + L.glist) : nullptr;
+    w.glcnt = big ? (u32 *)(base + L.glcnt) : nullptr;
+    w.hkg = big ? (u64 *)(base + L.hkg) : nullptr;
+    w.hig = big ? (u32 *)(base + L.hig) : nullptr;
+    w.hpg = big ? (u32 *)(base + L.hpg) : nullptr;
     if (debug_fail) w.cap_ft = 1;  // the first plan overflows the finish-tile table: the failure path, on demand
     if (err_word_out) *err_word_out = &w.ctl->err;
 
     HIP_TRY(hipMemsetAsync(base + L.clear_from, 0, L.clear_bytes, s));
     const u32 g_region = L.regions < 2048u ? L.regions : 2048u;
-    if (!few_repeats) hipLaunchKernelGGL(k_sniff, dim3(1), dim3(SNIFF_THREADS), 0, s, w);
-    hipLaunchKernelGGL(k_strip, dim3(g_region), dim3(WG), 0, s, w);
+    if (big) {
+        HIP_TRY(hipMemsetAsync(base + L.gk, 0xFF, (size_t)G_SLOTS * sizeof(u64), s));  // EMPTY
+        HIP_TRY(hipMemsetAsync(base + L.gc, 0, L.gzero_bytes, s));
+        hipLaunchKernelGGL(k_sniff_count, dim3(BIG_WGS), dim3(SNIFF_THREADS), 0, s, w);
+        hipLaunchKernelGGL(k_sniff_hist, dim3(64), dim3(1024), 0, s, w);
+        hipLaunchKernelGGL(k_sniff_pick, dim3(64), dim3(1024), 0, s, w);
+        hipLaunchKernelGGL(k_sniff_sort, dim3(1), dim3(1024), 0, s, w);
+        hipLaunchKernelGGL(k_strip<true>, dim3(g_region), dim3(WG), 0, s, w);
+        hipLaunchKernelGGL(k_heavy_prefix, dim3(1), dim3(1024), 0, s, w);
+    } else {
+        if (!few_repeats) hipLaunchKernelGGL(k_sniff, dim3(1), dim3(SNIFF_THREADS), 0, s, w);
+        hipLaunchKernelGGL(k_strip<false>, dim3(g_region), dim3(WG), 0, s, w);
+    }
     hipLaunchKernelGGL(k_scatter<true>, dim3(g_region), dim3(WG), 0, s, w, 0);
     const u32 max_tiles = (u32)(n / TILE + 1);
     // Levels 1 .. deep_from - 1 are launches over all tiles of all segments; what is still too large then is
@@ -1506,8 +1815,13 @@ int mc_sort_keys(const uint64_t *in, uint64_t n, uint64_t *out, void *workspace,
     }
     if (debug_fail) hipLaunchKernelGGL(k_force_error, dim3(1), dim3(1), 0, s, w.ctl);
     const u32 g_ft = L.cap_ft < 1024u ? L.cap_ft : 1024u;
-    hipLaunchKernelGGL(k_finish, dim3(g_ft), dim3(WG), 0, s, w);
-    if (!few_repeats) hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, s, w);  // (no heavy values: no runs)
+    if (big) {
+        hipLaunchKernelGGL(k_finish<true>, dim3(g_ft), dim3(WG), 0, s, w);
+        hipLaunchKernelGGL(k_fill<true>, dim3(1024), dim3(256), 0, s, w);
+    } else {
+        hipLaunchKernelGGL(k_finish<false>, dim3(g_ft), dim3(WG), 0, s, w);
+        if (!few_repeats) hipLaunchKernelGGL(k_fill<false>, dim3(1024), dim3(256), 0, s, w);  // (no heavy values: no runs)
+    }
     HIP_TRY(hipGetLastError());
     return MC_OK;
 }

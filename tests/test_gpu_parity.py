@@ -674,6 +674,59 @@ def test_rank_key_distributions():
             assert float(((rk.positions - ref).abs() / ref).max()) < REL, name
 
 
+def test_rank_large_search_for_heavy_values(big_model):
+    """From 2^26 keys on the rank build counts a 2^19-key sample over several workgroups and takes up to 3072
+    values out of the sort (csrc/mc_sort.hip: k_sniff_count .. k_sniff_sort, k_strip<BIG>, k_finish<BIG>,
+    k_fill<BIG>); mc_rank_debug_search(1) asks for that from 2^22 keys on, (2) never.  Either way: torch.sort's
+    keys bit for bit, and the same positions bit for bit (the scan sees the same sorted keys).  Once at a size
+    that takes the large search by itself."""
+    from montecarlo_amd import _native as nv
+    m, _ = big_model
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    n = (1 << 22) + 4097
+    few = torch.randint(0, 2500, (n,), generator=g).double() / 8 + 2
+    cases = {
+        "model samples": m._dev.sample(n, 7)["ml2p"],
+        "all distinct": torch.rand(n, generator=g, dtype=torch.float64) * 90,
+        "2500 values": few,
+        "one value": torch.full((n,), 7.25, dtype=torch.float64),
+        # more candidates than the list holds, every second key distinct
+        "10000 values and noise": torch.where(torch.rand(n, generator=g) < 0.5,
+                                              torch.randint(0, 10000, (n,), generator=g).double() + 3,
+                                              torch.rand(n, generator=g, dtype=torch.float64) * 10000 + 3),
+        # heavy values that differ in their lowest bits only, and the empty marker's neighbours
+        "adjacent bit patterns": (torch.randint(0, 3000, (n,), generator=g) + 0x4030000000000000).view(torch.float64),
+        "top of the range": (0x7FEFFFFFFFFFFFFF - torch.randint(0, 50, (n,), generator=g)).view(torch.float64),
+    }
+    found = {}
+    for name, keys in cases.items():
+        keys = keys.contiguous().to(dev)
+        want = torch.sort(keys.view(torch.int64))[0]
+        got = {}
+        for mode in (1, 2):
+            nv.lib.mc_rank_debug_search(mode)
+            try:
+                rk = DeviceRank(keys)
+                info = rk.check()
+            finally:
+                nv.lib.mc_rank_debug_search(0)
+            assert info["error"] == 0, (name, mode)
+            assert torch.equal(rk.keys_sorted.view(torch.int64), want), (name, mode)
+            got[mode] = (rk.positions.view(torch.int64).clone(), info)
+        if name != "top of the range":                                      # (weights overflow there: NaN != NaN)
+            assert torch.equal(got[1][0], got[2][0]), name
+        found[name] = (got[1][1]["heavy_values"], got[2][1]["heavy_values"])
+    assert found["model samples"][0] > 1024 >= found["model samples"][1] > 100     # the larger list is in use
+    assert found["2500 values"][0] > 2000 and found["all distinct"] == (0, 0) and found["one value"] == (1, 1)
+    n = (1 << 26) + 77                                                      # by size
+    keys = m._dev.sample(n, 9)["ml2p"]
+    rk = DeviceRank(keys)
+    info = rk.check()
+    assert info["error"] == 0 and info["heavy_values"] > 1024
+    assert torch.equal(rk.keys_sorted.view(torch.int64), torch.sort(keys.view(torch.int64))[0])
+
+
 def test_sort_and_order_fuzz():
     """Differential fuzz (scripts/sort_fuzz.py: random sizes up to 3e6, random mixtures of ties, clusters at several
     scales, single-bit keys, full bit patterns, runs, order words) of the key sort and of mc_order_keys against

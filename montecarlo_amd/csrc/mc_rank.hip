@@ -33,7 +33,8 @@ typedef unsigned int u32;
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 8;  // (k_positions pads its LDS tile for exactly 8)
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
-constexpr int SCAN_MAX_BLOCKS = 2048;
+constexpr int SCAN_MAX_BLOCKS = 16384;      // chunks of the scan (large inputs; 2048 up to 2^25 keys)
+constexpr int SCAN_SMALL_BLOCKS = 2048;
 
 // ---- positions: prefix sum of 2^(key - log2 n_global) ------------------------------------------
 // Exclusive prefix of `v` over the workgroup (and the workgroup total).  The exclusive value is
@@ -61,12 +62,54 @@ __device__ __forceinline__ double block_exclusive_scan(double v, double *wave_to
     return off + excl;
 }
 
+// A tile whose first and last key are the same bit pattern holds ONE value (the keys are sorted): its weights are
+// not read and summed but written down, (j + 1) * w after j + 1 of them -- k_weight_sums and k_positions use the
+// same expression, so the carry out of such a tile IS its last position.  Sampled scores are mostly long runs of
+// few values (81 % of the headline keys, 94 % at 1.25e9): the scan reads a fraction of the keys.  Which tiles of
+// a chunk are such tiles is found first, one tile per lane (one round trip to memory for the whole chunk: asked
+// tile by tile, that question was a chain of 300 dependent loads per workgroup at 1.25e9 keys).
+constexpr int SCAN_CHUNK_TILES = 1024;  // tiles per chunk at most: n < 2^32 keys over SCAN_MAX_BLOCKS chunks
+
+__device__ __forceinline__ bool same_bits(double a, double b) {
+    return __double_as_longlong(a) == __double_as_longlong(b);
+}
+
+// first[j] = first key of tile j of [lo, hi); bit j of mixed = the tile holds more than one value
+__device__ __forceinline__ void look_at_tiles(const double *__restrict__ keys, u64 lo, u64 hi, double *first,
+                                              u32 *mixed) {
+    const u32 ntiles = (u32)((hi - lo + SCAN_TILE - 1) / SCAN_TILE);
+    for (u32 j = threadIdx.x; j < (u32)SCAN_CHUNK_TILES / 32; j += SCAN_THREADS) mixed[j] = 0;
+    __syncthreads();
+    for (u32 j = threadIdx.x; j < ntiles; j += SCAN_THREADS) {
+        const u64 t0 = lo + (u64)j * SCAN_TILE, t1 = min(hi, t0 + SCAN_TILE);
+        const double a = keys[t0], b = keys[t1 - 1];
+        first[j] = a;
+        if (!same_bits(a, b)) atomicOr(&mixed[j >> 5], 1u << (j & 31u));
+    }
+    __syncthreads();
+}
+
 __global__ void __launch_bounds__(SCAN_THREADS) k_weight_sums(const double *__restrict__ keys, u64 n, u64 chunk,
                                                                double logn, double *__restrict__ partials) {
     __shared__ double wave_tot[SCAN_THREADS / 64];
+    __shared__ double first[SCAN_CHUNK_TILES];
+    __shared__ u32 mixed[SCAN_CHUNK_TILES / 32];
     const u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
     double s = 0.0;
-    for (u64 i = lo + threadIdx.x; i < hi; i += SCAN_THREADS) s += exp2(keys[i] - logn);
+    if (lo < hi) {
+        look_at_tiles(keys, lo, hi, first, mixed);
+        const u32 ntiles = (u32)((hi - lo + SCAN_TILE - 1) / SCAN_TILE);
+        for (u32 j = 0; j < ntiles; ++j) {  // mixed tiles: all lanes, in order
+            if (!((mixed[j >> 5] >> (j & 31u)) & 1u)) continue;
+            const u64 t0 = lo + (u64)j * SCAN_TILE, t1 = min(hi, t0 + SCAN_TILE);
+            for (u64 i = t0 + threadIdx.x; i < t1; i += SCAN_THREADS) s += exp2(keys[i] - logn);
+        }
+        for (u32 j = threadIdx.x; j < ntiles; j += SCAN_THREADS) {  // one-value tiles: a lane each
+            if ((mixed[j >> 5] >> (j & 31u)) & 1u) continue;
+            const u64 t0 = lo + (u64)j * SCAN_TILE, t1 = min(hi, t0 + SCAN_TILE);
+            s += (double)(t1 - t0) * exp2(first[j] - logn);
+        }
+    }
     double tot;
     (void)block_exclusive_scan(s, wave_tot, tot);
     if (threadIdx.x == 0) partials[blockIdx.x] = tot;
@@ -101,7 +144,24 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_positions(const double *__rest
     const u64 lo = (u64)blockIdx.x * chunk, hi = min(n, lo + chunk);
     // a sort whose tables overflowed (error word set, csrc/mc_sort.hip) must not pass for a result
     double carry = *err ? __longlong_as_double(0x7FF8000000000000ll) : partials[blockIdx.x];
-    for (u64 t0 = lo; t0 < hi; t0 += SCAN_TILE) {
+    __shared__ double first[SCAN_CHUNK_TILES];
+    __shared__ u32 mixed[SCAN_CHUNK_TILES / 32];
+    if (lo >= hi) return;
+    look_at_tiles(keys, lo, hi, first, mixed);  // (see k_weight_sums)
+    u32 j = 0;
+    for (u64 t0 = lo; t0 < hi; t0 += SCAN_TILE, ++j) {
+        const u64 t1 = min(hi, t0 + SCAN_TILE);
+        const bool one_value = !((mixed[j >> 5] >> (j & 31u)) & 1u);
+        const double w1 = exp2(first[j] - logn);
+        if (one_value) {  // (the same decision in every lane: no lane waits at a barrier below)
+#pragma unroll
+            for (int r = 0; r < SCAN_ITEMS; ++r) {
+                const u32 e = r * SCAN_THREADS + threadIdx.x;
+                if (t0 + e < t1) pos[t0 + e] = carry + (double)(e + 1) * w1;
+            }
+            carry += (double)(t1 - t0) * w1;
+            continue;
+        }
         double k[SCAN_ITEMS];
 #pragma unroll
         for (int r = 0; r < SCAN_ITEMS; ++r) {
@@ -159,7 +219,10 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 u32 scan_blocks(u64 n) {
     u64 tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
-    return (u32)(tiles < (u64)SCAN_MAX_BLOCKS ? (tiles ? tiles : 1) : SCAN_MAX_BLOCKS);
+    // large inputs: the tail of the sorted keys (distinct values, every tile read) fills whole chunks, and with 2048
+    // chunks of 300 tiles those were 120 workgroups streaming 5 MB each while the rest had finished
+    const u64 most = n <= (1ull << 25) ? (u64)SCAN_SMALL_BLOCKS : (u64)SCAN_MAX_BLOCKS;
+    return (u32)(tiles < most ? (tiles ? tiles : 1) : most);
 }
 
 std::atomic<int> g_debug_fail{0};
@@ -213,6 +276,10 @@ extern "C" int mc_rank_build(const double *keys_in, uint64_t n, uint64_t n_globa
     const u32 sb = scan_blocks(n);
     const u64 stiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     const u64 schunk = ((stiles + sb - 1) / sb) * SCAN_TILE;
+    if (schunk / SCAN_TILE > (u64)SCAN_CHUNK_TILES) {  // (cannot happen below 2^32 keys)
+        mc_set_error("mc_rank_build: %llu tiles per scan chunk", (unsigned long long)(schunk / SCAN_TILE));
+        return MC_ERR_ARG;
+    }
     hipLaunchKernelGGL(k_weight_sums, dim3(sb), dim3(SCAN_THREADS), 0, s, (const double *)keys_sorted, (u64)n, schunk,
                        logn, partials);
     hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(SCAN_THREADS), 0, s, partials, sb);

@@ -6,8 +6,10 @@
 // copies of 240 of them), and the sort is keys-only: equal keys are indistinguishable, nothing has to be
 // stable.  The sort is built for that and degrades gracefully to any key set:
 //
-//   k_sniff    one workgroup samples 4096 keys and lists the values seen at least 4 times ("heavy", <= 1024,
-//              sorted).
+//   k_sniff    one workgroup counts a sample of 16384 keys and lists the values seen at least 5 times ("heavy",
+//              <= 1024, sorted).  From 2^26 keys on the sample is 2^19 keys, counted by 32 workgroups into a
+//              table in the workspace (k_sniff_count / _hist / _pick / _sort), the list holds up to 3072 values
+//              and comes with a hash set in which a value lies in its home slot or the next one.
 //   k_strip    one read of all keys: a key equal to a heavy value is COUNTED, not moved (lookup in an LDS hash
 //              set); the others (the "tail") are written compacted, region by region, and their top-byte
 //              histograms are taken on the way.  No heavy values found: nothing is copied.
@@ -20,9 +22,12 @@
 //              (tile, bin) -- the order inside a bin is irrelevant -- so no workgroup ever waits for another
 //              one: there is no look-back chain, no spinning, no residency assumption; every kernel makes
 //              progress beside any other work on the GPU.
+//   k_deep     (up to 2^25 keys) two launched levels; what is still too large then is finished by one workgroup
+//              per segment through all its remaining levels.
 //   k_finish   sorts a tile of <= 4096 keys in LDS: buckets them linearly over [min, max] (4096 buckets, ~1
-//              key each), ranks inside small buckets by counting, walks the distinct values of large ones, and
-//              writes every key at its final index = its rank in the tail + the copies of smaller heavy values.
+//              key each), ranks inside small buckets by counting, larger ones by one wave, and a bucket beyond
+//              that over its own extremes in a later round; writes every key at its final index = its rank in
+//              the tail + the copies of smaller heavy values.
 //   k_fill     writes the runs of the heavy values into the gaps left for them.
 //
 // All hand-offs between workgroups go through kernel boundaries on the stream.  Every store that depends on a

@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""How much of a model's sampled keys the K commonest values hold (K = 256 .. 2^20), for the v2 and the backoff
+model: the numbers behind the size of the large search's list.  Usage: key_coverage.py [n]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("TQDM_DISABLE", "1")
 import torch
 from montecarlo_amd import synth

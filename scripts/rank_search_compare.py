@@ -1,5 +1,10 @@
+#!/usr/bin/env python3
+"""The rank build with the small and with the large search for heavy values (mc_rank_debug_search), side by side.
+  rank_search_compare.py check            both against torch.sort and against each other on seven key sets at three sizes
+  rank_search_compare.py time N [N ...]   both timed on the samples of the v2 and the backoff model at N keys
+(profiles/r02_h_rank_build_small_vs_large_search.txt is `time 1e7 67108864 1.25e9`.)"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("TQDM_DISABLE", "1")
 import torch
 from montecarlo_amd import synth, _native as nv

@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Per-kernel time of single rank builds out of a rocprofv3 --kernel-trace database (the default .db output):
+  trace_db_breakdown.py <results.db> <build index> [...]   (builds are counted by their first k_sniff / k_sniff_count)"""
 import sqlite3, sys, re
 db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
 rows = list(cur.execute("select name, start, end from kernels order by start"))

@@ -1115,9 +1115,13 @@ static int launch_sample(mc_model *m, bool inject, const SampleArgs &a_in, hipSt
         HIP_TRY(hipGetLastError());
         return MC_OK;
     }
-    // Workgroups of 256 lanes; 16 per CU, of which 8 are resident at a time: a workgroup owns a
-    // contiguous range of sample ids, and the second half of the grid evens out the ranges whose
-    // strings came out long (measured: 16 per CU 12 % faster than 8, 32 and 64 slower again).
+    // Workgroups of 256 lanes; 14 per CU, of which 8 are resident at a time: a workgroup owns a
+    // contiguous range of sample ids, and the second, partial generation of workgroups takes the slots
+    // the first leaves as its waves thin out (the kernel is bound by VALU issue; a wave whose lanes are
+    // mostly done costs as much issue as a full one).  Measured at 1e7 samples with the round-2 kernel
+    // (scripts/exp_sample_grid.py): 8 per CU 0.497 ms, 12 0.421, 13 0.415, 14 0.410, 15 0.444, 16 0.437,
+    // 20 0.426, 32 0.459; 14 is also the best of 12/14/16/20 on the v2, the fixed-order and a smaller
+    // backoff model (4-10 % under 16).
     // 15 KB of LDS per workgroup hold the head of the draw table (with the 4 KB of the waves' key rings 8
     // workgroups fit a CU; it serves about half of the draws of the headline model; 40 KB costs more in
     // occupancy than it saves).  One or two
@@ -1125,7 +1129,7 @@ static int launch_sample(mc_model *m, bool inject, const SampleArgs &a_in, hipSt
     // (results never depend on them: tests/test_gpu_parity.py).  Each workgroup's share of the
     // sample ids must fit u32.
     static const int env_nc = getenv("MC_SAMPLE_CHAINS") ? atoi(getenv("MC_SAMPLE_CHAINS")) : 1;
-    static const int env_wg = getenv("MC_SAMPLE_WG_PER_CU") ? atoi(getenv("MC_SAMPLE_WG_PER_CU")) : 16;
+    static const int env_wg = getenv("MC_SAMPLE_WG_PER_CU") ? atoi(getenv("MC_SAMPLE_WG_PER_CU")) : 14;
     static const int env_hot = getenv("MC_SAMPLE_HOT_KB") ? atoi(getenv("MC_SAMPLE_HOT_KB")) : 15;
     const int nc = inject ? 1 : env_nc;
     {
@@ -1134,7 +1138,7 @@ static int launch_sample(mc_model *m, bool inject, const SampleArgs &a_in, hipSt
     }
     const size_t lds = (size_t)a.hot_recs * sizeof(DrawRec);
     unsigned long long want = (a.count + 64ull * nc - 1) / (64ull * nc);
-    unsigned long long cap = (unsigned long long)m->n_cu * (env_wg > 0 ? env_wg : 16);
+    unsigned long long cap = (unsigned long long)m->n_cu * (env_wg > 0 ? env_wg : 14);
     unsigned long long grid = want < cap ? want : cap;
     while ((a.count + grid - 1) / grid > 0x7FFFFFFFull) grid *= 2;
     dim3 g((unsigned)grid), b(256);

@@ -1191,9 +1191,13 @@ extern "C" int mc_score(mc_model *m, const uint32_t *syms, const uint64_t *off, 
                      "mc_score_words; BPE-PCFG: mc_score_bpe)");
         return MC_ERR_ARG;
     }
-    unsigned long long want = (count + 255) / 256, cap = (unsigned long long)m->n_cu * 8;
+    static const int env_swg = getenv("MC_SCORE_WG_PER_CU") ? atoi(getenv("MC_SCORE_WG_PER_CU")) : 8;
+    unsigned long long want = (count + 255) / 256, cap = (unsigned long long)m->n_cu * (env_swg > 0 ? env_swg : 8);
     dim3 g((unsigned)(want < cap ? want : cap)), b(256);
-    static const int env_np = getenv("MC_SCORE_CHAINS") ? atoi(getenv("MC_SCORE_CHAINS")) : 2;
+    // passwords a lane walks at a time: one on the dense table (scripts/exp_score_grid.py, 1e6 passwords: the bench's
+    // test set 0.040 ms against 0.051 with two, distinct strings 0.052 against 0.059), two on the hash path
+    static const int env_np_given = getenv("MC_SCORE_CHAINS") ? atoi(getenv("MC_SCORE_CHAINS")) : 0;
+    const int env_np = env_np_given > 0 ? env_np_given : (m->dev.dense ? 1 : 2);
     const unsigned long long *o64 = (const unsigned long long *)off;
     hipStream_t st = (hipStream_t)stream;
     if (m->dev.dense) {

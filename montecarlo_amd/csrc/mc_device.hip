@@ -85,6 +85,8 @@ struct SampleArgs {
     uint32_t *out_len, *out_draws, *out_syms;
     uint32_t max_draws, sym_stride;
     uint32_t hot_recs;  // draw-table records cached in LDS by k_sample
+    float skew;         // k_sample: workgroup i of g owns the ids between count * f(i / g) and count * f((i + 1) / g),
+                        // f(x) = (1 + skew) x - skew x^2: the first workgroups' ranges are (1 + skew) x the mean, the last (1 - skew) x
 };
 
 constexpr uint32_t PH_M0 = 0xD2511F53u, PH_M1 = 0xCD9E8D57u, PH_W0 = 0x9E3779B9u, PH_W1 = 0xBB67AE85u;
@@ -148,9 +150,21 @@ __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
     for (uint32_t i = threadIdx.x; i < a.hot_recs; i += blockDim.x) hot[i] = ((const DrawRec *)m.draw)[i];
     // a workgroup owns `per` consecutive sample ids (a multiple of 16, so that every chunk a wave takes starts on
     // a line of out_ml2p when that array is 128-byte aligned); its waves take them 64 at a time from a cursor
-    const unsigned long long per = ((a.count + gridDim.x - 1) / gridDim.x + (LINE_KEYS - 1)) & ~(unsigned long long)(LINE_KEYS - 1);
-    const unsigned long long b0 = min(a.count, (unsigned long long)blockIdx.x * per);
-    const unsigned long long b1 = min(a.count, b0 + per);
+    unsigned long long b0, b1;
+    if (a.skew > 0.0f) {
+        auto bound = [&](unsigned int i) -> unsigned long long {
+            if (i >= gridDim.x) return a.count;
+            const double x = (double)i / (double)gridDim.x;
+            const unsigned long long v = (unsigned long long)((double)a.count * ((1.0 + (double)a.skew) * x - (double)a.skew * x * x));
+            return min(a.count, v & ~(unsigned long long)(LINE_KEYS - 1));
+        };
+        b0 = bound(blockIdx.x);
+        b1 = bound(blockIdx.x + 1);
+    } else {
+        const unsigned long long per = ((a.count + gridDim.x - 1) / gridDim.x + (LINE_KEYS - 1)) & ~(unsigned long long)(LINE_KEYS - 1);
+        b0 = min(a.count, (unsigned long long)blockIdx.x * per);
+        b1 = min(a.count, b0 + per);
+    }
     const unsigned int nblk = (unsigned int)(b1 - b0);
     const unsigned int wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     double *const rkeys = ring_keys[wid];
@@ -1121,7 +1135,11 @@ static int launch_sample(mc_model *m, bool inject, const SampleArgs &a_in, hipSt
     // mostly done costs as much issue as a full one).  Measured at 1e7 samples with the round-2 kernel
     // (scripts/exp_sample_grid.py): 8 per CU 0.497 ms, 12 0.421, 13 0.415, 14 0.410, 15 0.444, 16 0.437,
     // 20 0.426, 32 0.459; 14 is also the best of 12/14/16/20 on the v2, the fixed-order and a smaller
-    // backoff model (4-10 % under 16).
+    // backoff model (4-10 % under 16).  The ranges are not equal: they shrink linearly from 1.55 x the mean for the
+    // first workgroup to 0.45 x for the last (SampleArgs.skew), so that workgroups end one after the other
+    // instead of a generation at a time and the slots they free are taken at once: 0.410 -> 0.382 ms at 1e7
+    // samples, 3.46 -> 3.21 ms at 1e8, 5-7 % on the fixed-order and the smaller backoff model, nothing on the
+    // v2 model (0.25 .. 0.75 and exponentially shrinking ranges at 14 .. 32 workgroups a CU were tried).
     // 15 KB of LDS per workgroup hold the head of the draw table (with the 4 KB of the waves' key rings 8
     // workgroups fit a CU; it serves about half of the draws of the headline model; 40 KB costs more in
     // occupancy than it saves).  One or two
@@ -1136,6 +1154,8 @@ static int launch_sample(mc_model *m, bool inject, const SampleArgs &a_in, hipSt
         unsigned long long recs = (unsigned long long)(env_hot < 0 ? 0 : env_hot > 150 ? 150 : env_hot) * 1024 / 16;
         a.hot_recs = (uint32_t)(recs < m->n_draw ? recs : m->n_draw);
     }
+    static const float env_skew = getenv("MC_SAMPLE_SKEW") ? (float)atof(getenv("MC_SAMPLE_SKEW")) : 0.55f;
+    a.skew = env_skew < 0.0f ? 0.0f : env_skew > 0.95f ? 0.95f : env_skew;
     const size_t lds = (size_t)a.hot_recs * sizeof(DrawRec);
     unsigned long long want = (a.count + 64ull * nc - 1) / (64ull * nc);
     unsigned long long cap = (unsigned long long)m->n_cu * (env_wg > 0 ? env_wg : 14);

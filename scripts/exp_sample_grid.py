@@ -30,7 +30,10 @@ for i in range(100): m._dev.sample(n, 5, first_id=i * n, out=out)
 b.record(); torch.cuda.synchronize()
 print("%%.4f ms  checksum %%d" %% (a.elapsed_time(b) / 100, int(out.view(torch.int64).sum().item())))
 ''' % root
-for wg in sys.argv[1:]:
+for spec in sys.argv[1:]:
+    wg, _, skew = spec.partition(":")
     e = dict(os.environ); e["MC_SAMPLE_WG_PER_CU"] = wg
+    if skew:
+        e["MC_SAMPLE_SKEW"] = skew
     r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=120)
-    print("workgroups per CU", wg, r.stdout.strip().split("\n")[-1] if r.stdout.strip() else r.stderr[-300:], flush=True)
+    print("workgroups per CU", spec, r.stdout.strip().split("\n")[-1] if r.stdout.strip() else r.stderr[-300:], flush=True)

@@ -171,11 +171,14 @@ def main():
     q_pos = [torch.empty(T, dtype=torch.float64, device=dev) for _ in range(2)]
     t_sorted = [torch.empty(T, dtype=torch.float64, device=dev) for _ in range(2)]
     t_order = [torch.empty(T, dtype=torch.int32, device=dev) for _ in range(2)]
-    g_rank = [torch.empty(T, dtype=torch.int64, device=dev) for _ in range(2)]
-    g_exact = [torch.empty(1, dtype=torch.int64, device=dev) for _ in range(2)]
-    host = [{"rank": torch.empty(T, dtype=torch.int64).pin_memory(), "order": torch.empty(T, dtype=torch.int32).pin_memory(),
-             "ml2p": torch.empty(T, dtype=torch.float64).pin_memory(), "exact": torch.empty(1, dtype=torch.int64).pin_memory()}
-            for _ in range(2)]
+    # (the guess numbers and the count of those that are exact share one buffer: ONE copy to the host a step)
+    g_both = [torch.empty(T + 1, dtype=torch.int64, device=dev) for _ in range(2)]
+    g_rank = [b[:T] for b in g_both]
+    g_exact = [b[T:] for b in g_both]
+    h_both = [torch.empty(T + 1, dtype=torch.int64).pin_memory() for _ in range(2)]
+    host = [{"rank": h_both[i][:T], "order": torch.empty(T, dtype=torch.int32).pin_memory(),
+             "ml2p": torch.empty(T, dtype=torch.float64).pin_memory(), "exact": h_both[i][T:]}
+            for i in range(2)]
     ws_order = torch.empty(nv.lib.mc_order_workspace_bytes(T), dtype=torch.uint8, device=dev)
     ws_gn = torch.empty(nv.lib.mc_guess_numbers_workspace_bytes(T), dtype=torch.uint8, device=dev)
     reduced, copied, copied_on = [None, None], [None, None], [None, None]
@@ -280,8 +283,7 @@ def main():
             # the guess numbers travel every step (8 B per test password: they are what the samples decide); the
             # order of the test set and its sorted scores do not depend on the samples -- a caller fetches them
             # once per test set, here after the timed region for the checks (--d2h-all copies them every step)
-            host[slot]["rank"].copy_(g_rank[slot], non_blocking=True)
-            host[slot]["exact"].copy_(g_exact[slot], non_blocking=True)
+            h_both[slot].copy_(g_both[slot], non_blocking=True)
             if args.d2h_all:
                 host[slot]["order"].copy_(t_order[slot], non_blocking=True)
                 host[slot]["ml2p"].copy_(t_sorted[slot], non_blocking=True)

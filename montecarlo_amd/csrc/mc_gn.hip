@@ -247,11 +247,11 @@ __device__ __forceinline__ double gn_estimate(const double *pos, const u64 *cnt,
     return (cnt ? cnt[i] > 0 : p > 0.0) ? p : 1.0;
 }
 
-// ceil(est) - i * add as int64, or GN_NEG from the first estimate that does not fit (its index goes to *inexact)
-__device__ __forceinline__ i64 gn_term(const double *pos, const u64 *cnt, u64 i, int add1, u64 *inexact) {
+// ceil(est) - i * add as int64, or GN_NEG for an estimate that does not fit (first_bad keeps the lowest such index)
+__device__ __forceinline__ i64 gn_term(const double *pos, const u64 *cnt, u64 i, int add1, u64 &first_bad) {
     const double c = ceil(gn_estimate(pos, cnt, i));
     if (!(c < 4611686018427387904.0)) {  // >= 2^62, or NaN
-        atomicMin(inexact, i);
+        first_bad = i < first_bad ? i : first_bad;
         return GN_NEG;
     }
     const i64 v = (i64)c - (add1 ? (i64)(i + 1) : 0);
@@ -280,44 +280,80 @@ __device__ __forceinline__ i64 block_max_scan_excl(i64 v, i64 *wave_tot, i64 &bl
     return off > excl ? off : excl;
 }
 
+// Two launches.  k_gn_chunk_max: per chunk, the largest term and the lowest index whose estimate does not fit int64.
+// k_gn_ranks: every workgroup folds the chunks before it (a maximum of integers: exact in any order, so no scan kernel
+// in between) and all chunks' lowest indices, then scans its own chunk; workgroup 0 writes the count of exact ranks.
 __global__ void __launch_bounds__(GN_THREADS) k_gn_chunk_max(const double *__restrict__ pos, const u64 *__restrict__ cnt,
                                                              u64 t, u64 chunk, int add1, i64 *__restrict__ partials,
-                                                             u64 *inexact) {
+                                                             u64 *__restrict__ first_bad_of) {
     __shared__ i64 wave_tot[GN_THREADS / 64];
+    __shared__ u64 wave_bad[GN_THREADS / 64];
     const u64 lo = (u64)blockIdx.x * chunk, hi = lo + chunk < t ? lo + chunk : t;
     i64 m = GN_NEG;
+    u64 bad = ~0ull;
     for (u64 i = lo + threadIdx.x; i < hi; i += GN_THREADS) {
-        const i64 v = gn_term(pos, cnt, i, add1, inexact);
+        const i64 v = gn_term(pos, cnt, i, add1, bad);
         m = v > m ? v : m;
     }
     i64 tot;
     (void)block_max_scan_excl(m, wave_tot, tot);
-    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
-}
-
-__global__ void __launch_bounds__(GN_THREADS) k_gn_scan_partials(i64 *partials, u32 nb) {
-    __shared__ i64 wave_tot[GN_THREADS / 64];
-    const u32 per = (nb + GN_THREADS - 1) / GN_THREADS;
-    const u32 lo = threadIdx.x * per < nb ? threadIdx.x * per : nb, hi = lo + per < nb ? lo + per : nb;
-    i64 m = GN_NEG;
-    for (u32 i = lo; i < hi; ++i) m = partials[i] > m ? partials[i] : m;
-    i64 tot;
-    i64 run = block_max_scan_excl(m, wave_tot, tot);
-    for (u32 i = lo; i < hi; ++i) {
-        const i64 v = partials[i];
-        partials[i] = run;  // exclusive
-        run = v > run ? v : run;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        const u64 u = __shfl_xor(bad, o);
+        bad = u < bad ? u : bad;
+    }
+    if ((threadIdx.x & 63) == 0) wave_bad[threadIdx.x >> 6] = bad;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < GN_THREADS / 64; ++w) bad = wave_bad[w] < bad ? wave_bad[w] : bad;
+        partials[blockIdx.x] = tot;
+        first_bad_of[blockIdx.x] = bad;
     }
 }
 
 __global__ void __launch_bounds__(GN_THREADS) k_gn_ranks(const double *__restrict__ pos, const u64 *__restrict__ cnt,
                                                          u64 t, u64 chunk, int add1, const i64 *__restrict__ partials,
-                                                         u64 *inexact, i64 *__restrict__ rank) {
+                                                         const u64 *__restrict__ first_bad_of, u32 nb, u64 *out_exact,
+                                                         i64 *__restrict__ rank) {
     __shared__ i64 wave_tot[GN_THREADS / 64];
+    __shared__ u64 wave_bad[GN_THREADS / 64];
+    __shared__ i64 s_carry;
+    __shared__ u64 s_exact;
     const u64 lo = (u64)blockIdx.x * chunk, hi = lo + chunk < t ? lo + chunk : t;
-    const u64 exact = *inexact;  // (final: k_gn_chunk_max has seen every term)
-    i64 carry = partials[blockIdx.x];
+    {
+        i64 m = GN_NEG;
+        u64 bad = t;  // (no estimate out of range: all t ranks are exact)
+        for (u32 i = threadIdx.x; i < nb; i += GN_THREADS) {
+            if (i < blockIdx.x) m = partials[i] > m ? partials[i] : m;
+            bad = first_bad_of[i] < bad ? first_bad_of[i] : bad;
+        }
+#pragma unroll
+        for (int o = 32; o; o >>= 1) {
+            const i64 u = __shfl_xor(m, o);
+            m = u > m ? u : m;
+            const u64 b2 = __shfl_xor(bad, o);
+            bad = b2 < bad ? b2 : bad;
+        }
+        if ((threadIdx.x & 63) == 0) {
+            wave_tot[threadIdx.x >> 6] = m;
+            wave_bad[threadIdx.x >> 6] = bad;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < GN_THREADS / 64; ++w) {
+                m = wave_tot[w] > m ? wave_tot[w] : m;
+                bad = wave_bad[w] < bad ? wave_bad[w] : bad;
+            }
+            s_carry = m;
+            s_exact = bad;
+            if (blockIdx.x == 0) *out_exact = bad;
+        }
+        __syncthreads();
+    }
+    const u64 exact = s_exact;
+    i64 carry = s_carry;
     if (carry < 0) carry = 0;
+    u64 unused = ~0ull;
     for (u64 t0 = lo; t0 < hi; t0 += GN_TILE) {
         // a lane scans GN_ITEMS consecutive terms
         i64 v[GN_ITEMS];
@@ -325,7 +361,7 @@ __global__ void __launch_bounds__(GN_THREADS) k_gn_ranks(const double *__restric
 #pragma unroll
         for (int j = 0; j < GN_ITEMS; ++j) {
             const u64 i = t0 + (u64)threadIdx.x * GN_ITEMS + j;
-            v[j] = i < hi ? gn_term(pos, cnt, i, add1, inexact) : GN_NEG;
+            v[j] = i < hi ? gn_term(pos, cnt, i, add1, unused) : GN_NEG;
             m = v[j] > m ? v[j] : m;
             v[j] = m;  // inclusive within the lane
         }
@@ -345,8 +381,6 @@ __global__ void __launch_bounds__(GN_THREADS) k_gn_ranks(const double *__restric
         __syncthreads();
     }
 }
-
-__global__ void k_gn_init(u64 *inexact, u64 t) { *inexact = t; }
 
 }  // namespace
 
@@ -421,7 +455,7 @@ extern "C" int mc_order_keys(const double *x, uint64_t t, double *x_sorted, uint
 
 extern "C" size_t mc_guess_numbers_workspace_bytes(uint64_t t) {
     (void)t;
-    return align256(GN_MAX_BLOCKS * sizeof(i64)) + 256;
+    return 2 * align256(GN_MAX_BLOCKS * sizeof(i64)) + 256;  // per chunk: largest term, lowest index out of range
 }
 
 extern "C" int mc_guess_numbers(const double *pos, const uint64_t *cnt, uint64_t t, int add1, int64_t *out_rank,
@@ -431,8 +465,10 @@ extern "C" int mc_guess_numbers(const double *pos, const uint64_t *cnt, uint64_t
         return MC_ERR_ARG;
     }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_gn_init, dim3(1), dim3(1), 0, s, (u64 *)out_exact, (u64)t);
-    if (t == 0) return MC_OK;
+    if (t == 0) {
+        HIP_TRY(hipMemsetAsync(out_exact, 0, sizeof(uint64_t), s));
+        return MC_OK;
+    }
     if (!pos || !out_rank || !workspace) {
         mc_set_error("mc_guess_numbers: bad argument");
         return MC_ERR_ARG;
@@ -446,11 +482,11 @@ extern "C" int mc_guess_numbers(const double *pos, const uint64_t *cnt, uint64_t
     const u64 tiles = (t + GN_TILE - 1) / GN_TILE;
     const u32 nb = (u32)(tiles < (u64)GN_MAX_BLOCKS ? tiles : (u64)GN_MAX_BLOCKS);
     const u64 chunk = ((tiles + nb - 1) / nb) * GN_TILE;
+    u64 *first_bad_of = (u64 *)((char *)workspace + align256(GN_MAX_BLOCKS * sizeof(i64)));
     hipLaunchKernelGGL(k_gn_chunk_max, dim3(nb), dim3(GN_THREADS), 0, s, pos, (const u64 *)cnt, (u64)t, chunk, add1,
-                       partials, (u64 *)out_exact);
-    hipLaunchKernelGGL(k_gn_scan_partials, dim3(1), dim3(GN_THREADS), 0, s, partials, nb);
+                       partials, first_bad_of);
     hipLaunchKernelGGL(k_gn_ranks, dim3(nb), dim3(GN_THREADS), 0, s, pos, (const u64 *)cnt, (u64)t, chunk, add1,
-                       (const i64 *)partials, (u64 *)out_exact, (i64 *)out_rank);
+                       (const i64 *)partials, (const u64 *)first_bad_of, nb, (u64 *)out_exact, (i64 *)out_rank);
     HIP_TRY(hipGetLastError());
     return MC_OK;
 }

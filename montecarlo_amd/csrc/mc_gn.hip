@@ -40,15 +40,7 @@ constexpr i64 GN_NEG = -(1ll << 62);
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // fp64 bits -> a word whose unsigned order is the numeric order (-0.0 and 0.0 compare equal in Python: one word)
-__device__ __forceinline__ u64 order_bits(u64 b) {
-    if ((b << 1) == 0) b = 0;
-    return (b >> 63) ? ~b : (b | (1ull << 63));
-}
-
-__global__ void __launch_bounds__(256) k_order_prep(const u64 *__restrict__ x, u64 t, u64 *__restrict__ keys) {
-    for (u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x; p < t; p += (u64)gridDim.x * blockDim.x)
-        keys[p] = order_bits(x[p]);
-}
+__device__ __forceinline__ u64 order_bits(u64 b) { return mc_sort_order_word(b); }
 
 // words[p] = (index of the first sorted key equal to x[p]'s) << 32 | p.  The search runs in two stages: every
 // OW_STRIDE-th sorted key is staged in LDS and searched there, the rest of the search is confined to one stride of
@@ -410,8 +402,8 @@ extern "C" int mc_order_keys(const double *x, uint64_t t, double *x_sorted, uint
     u32 *failed = (u32 *)((char *)words_sorted + align256(t * sizeof(u64)));
     uint32_t *err1 = nullptr, *err2 = nullptr;
     const u32 g = (u32)((t + 255) / 256 < 2048 ? (t + 255) / 256 : 2048);
-    hipLaunchKernelGGL(k_order_prep, dim3(g), dim3(256), 0, s, (const u64 *)x, (u64)t, words_sorted);
-    int rc = mc_sort_keys((const uint64_t *)words_sorted, t, (uint64_t *)x_sorted, workspace, sort_bytes, &err1, 0, s);
+    // (the sort reads the scores as they are and maps them to order words on the way: no pass of our own for that)
+    int rc = mc_sort_keys((const uint64_t *)x, t, (uint64_t *)x_sorted, workspace, sort_bytes, &err1, MC_SORT_RAW_F64, s);
     if (rc != MC_OK) return rc;
     const u32 stride = (u32)((t + OW_LDS - 1) / OW_LDS) ? (u32)((t + OW_LDS - 1) / OW_LDS) : 1u;  // (t < 2^32)
     const u32 gw = (u32)((t + 2047) / 2048 < 512 ? (t + 2047) / 2048 : 512);

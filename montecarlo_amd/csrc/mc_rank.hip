@@ -200,18 +200,59 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_positions(const double *__rest
 }
 
 // ---- ml2p2rank for a batch ---------------------------------------------------------------------
+// One lane per test password: cnt = bisect_right(keys, x), pos = positions[cnt - 1].  A wave first narrows the range
+// for all its lanes together: the answers for its smallest and its largest x bracket every lane's answer, and each
+// of the two is found in rounds of 32 probes (5 rounds for 1e7 keys instead of 24 dependent reads a lane); test
+// passwords usually arrive in ascending order of x (mc_order_keys), so what is left to a lane is a few steps.
+// Any order of x is answered correctly (the bracket is wide then), NaN as by the plain search (cnt = n).
 __global__ void __launch_bounds__(256) k_query(const double *__restrict__ keys, const double *__restrict__ pos, u64 n,
                                                const double *__restrict__ x, u64 t, double *__restrict__ out_pos,
                                                u64 *__restrict__ out_cnt) {
-    for (u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x; q < t; q += (u64)gridDim.x * blockDim.x) {
-        const double v = x[q];
-        u64 lo = 0, hi = n;  // first index with keys[i] > v  (bisect_right)
-        while (lo < hi) {
-            const u64 mid = (lo + hi) >> 1;
-            if (keys[mid] > v) hi = mid; else lo = mid + 1;
+    const int lane = threadIdx.x & 63;
+    for (u64 q0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) - lane; q0 < t; q0 += (u64)gridDim.x * blockDim.x) {
+        const u64 q = q0 + lane;
+        const bool act = q < t;
+        const double v = act ? x[q] : 0.0;
+        // the wave's smallest and largest x (a NaN anywhere: no bracket)
+        double vmin = act ? v : __longlong_as_double(0x7FF0000000000000ll);
+        double vmax = act ? v : __longlong_as_double(0xFFF0000000000000ull);
+        bool odd = act && !(v == v);
+#pragma unroll
+        for (int o = 32; o; o >>= 1) {
+            const double a2 = __shfl_xor(vmin, o), b2 = __shfl_xor(vmax, o);
+            vmin = a2 < vmin ? a2 : vmin;
+            vmax = b2 > vmax ? b2 : vmax;
         }
-        if (out_cnt) out_cnt[q] = lo;
-        out_pos[q] = lo ? pos[lo - 1] : 0.0;
+        u64 lo = 0, hi = n;
+        if (__ballot(odd) == 0 && n > 4096) {
+            // lanes 0..31 look for vmin's answer, lanes 32..63 for vmax's: 32 probes split the current range
+            const double w = lane < 32 ? vmin : vmax;
+            const int sub = lane & 31;
+            u64 a = 0, b = n;  // the answer (first index with keys[i] > w) lies in [a, b]
+            while (b - a > 64) {
+                const u64 step = (b - a) / 33 + 1;
+                const u64 p = a + step * (u64)(sub + 1) - 1;  // probes a+step-1, a+2step-1, ...
+                const bool gt = p < b ? keys[p] > w : true;
+                const u64 bal = __ballot(gt);
+                const u32 half = lane < 32 ? (u32)bal : (u32)(bal >> 32);
+                const int first = half ? __ffs((int)half) - 1 : 32;  // first probe whose key is > w
+                // keys[p_first] > w: the answer is <= p_first; keys[p_{first-1}] <= w: the answer is > p_{first-1}
+                const u64 nb = first < 32 ? a + step * (u64)(first + 1) - 1 : b;
+                const u64 na = first > 0 ? a + step * (u64)first : a;
+                a = na;
+                b = nb < b ? nb : b;
+            }
+            lo = __shfl(a, 0);   // vmin's answer is at or after this: so is every lane's
+            hi = __shfl(b, 32);  // vmax's answer is at or before this
+        }
+        if (act) {
+            while (lo < hi) {  // first index with keys[i] > v  (bisect_right)
+                const u64 mid = (lo + hi) >> 1;
+                if (keys[mid] > v) hi = mid; else lo = mid + 1;
+            }
+            if (out_cnt) out_cnt[q] = lo;
+            out_pos[q] = lo ? pos[lo - 1] : 0.0;
+        }
     }
 }
 

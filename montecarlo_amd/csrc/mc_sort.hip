@@ -123,6 +123,8 @@ struct Ws {
     u64 *A, *B, *C;
     u32 n, region, regions;
     u32 cap_seg, cap_tile, cap_ft;
+    u32 raw_f64;     // the input is raw fp64 bit patterns of ANY sign: every read of `in` maps them to words whose
+                     // unsigned order is the numeric order (key_of), so the caller needs no pass of its own for that
     u32 *clear_from; // k_sniff clears the control tables itself (no memset launch before it): from here ...
     u32 clear_words; // ... this many words; 0: the host has done it
     // large inputs only (null otherwise)
@@ -137,6 +139,9 @@ struct Ws {
 };
 
 __device__ __forceinline__ u32 hset_hash(u64 k) { return (u32)((k * 0x9E3779B97F4A7C15ull) >> 40); }
+
+// fp64 bits -> a word whose unsigned order is the numeric order (mc_sort_order_word, mc_sort.h)
+__device__ __forceinline__ u64 key_of(u64 b) { return mc_sort_order_word(b); }
 
 // exclusive prefix of v over the workgroup (every thread calls); `wtot` holds NWAVE words
 __device__ __forceinline__ u32 wg_excl_scan(u32 v, u32 *wtot, u32 &total) {
@@ -206,8 +211,8 @@ constexpr int SNIFF_BLOCK = 16;  // consecutive keys per sampled block
 // One workgroup's SNIFF_S sample keys (block `block0 + i` of SNIFF_BLOCK keys starts at (block0 + i) * bstride),
 // counted per slot of the LDS tag table; slot[q] = the slot of key q, or 0xFFFFFFFF when it found no place.
 template <int PER>
-__device__ __forceinline__ void sniff_sample(const u64 *in, u64 bstride, u32 block0, u32 *tag, u32 *tc, u64 (&k)[PER],
-                                             u32 (&slot)[PER]) {
+__device__ __forceinline__ void sniff_sample(const u64 *in, bool raw, u64 bstride, u32 block0, u32 *tag, u32 *tc,
+                                             u64 (&k)[PER], u32 (&slot)[PER]) {
     // (blocks of consecutive keys: 1024 pages touched; every key at its own stride was one address translation
     // per key for this one compute unit, most of the kernel's time)
     constexpr int BLOCK = SNIFF_BLOCK;
@@ -216,6 +221,10 @@ __device__ __forceinline__ void sniff_sample(const u64 *in, u64 bstride, u32 blo
     for (int q = 0; q < PER; ++q) {
         const u32 block = (u32)((q * SNIFF_THREADS + tid) / BLOCK);
         k[q] = in[(u64)(block0 + block) * bstride + (u32)(tid % BLOCK)];
+    }
+    if (raw) {  // (uniform)
+#pragma unroll
+        for (int q = 0; q < PER; ++q) k[q] = key_of(k[q]);
     }
     // every key tries its home slot first, all PER attempts in flight together (one after the other they were PER
     // dependent LDS round trips); only a key that finds another value there walks on
@@ -265,7 +274,7 @@ __global__ void __launch_bounds__(SNIFF_THREADS) k_sniff(Ws w) {
     __syncthreads();
     u64 k[PER];
     u32 slot[PER];
-    sniff_sample<PER>(w.in, n / (SNIFF_S / SNIFF_BLOCK), 0u, tag, tc, k, slot);
+    sniff_sample<PER>(w.in, w.raw_f64 != 0, n / (SNIFF_S / SNIFF_BLOCK), 0u, tag, tc, k, slot);
     u32 bar = SNIFF_MIN;
     for (;;) {  // (uniform: every thread sees the same nlist)
         __syncthreads();
@@ -486,6 +495,10 @@ __global__ void __launch_bounds__(WG) k_strip(Ws w) {
         for (u32 c0 = 0; c0 < rn; c0 += TILE) {
 #pragma unroll
             for (int q = 0; q < ITEMS; ++q) k[q] = nk[q];
+            if (w.raw_f64) {  // (uniform)
+#pragma unroll
+                for (int q = 0; q < ITEMS; ++q) k[q] = key_of(k[q]);
+            }
             if (c0 + TILE < rn) {  // the next tile travels while this one is looked up
 #pragma unroll
                 for (int q = 0; q < ITEMS; ++q) {
@@ -576,7 +589,7 @@ __global__ void __launch_bounds__(SNIFF_THREADS) k_sniff_count(Ws w) {
     u64 k[PER];
     u32 slot[PER];
     // (the host launches this for n >= BIG_LAYOUT_N only: a block's stride is far above its 16 keys)
-    sniff_sample<PER>(w.in, w.n / (BLOCKS * gridDim.x), blockIdx.x * BLOCKS, tag, tc, k, slot);
+    sniff_sample<PER>(w.in, w.raw_f64 != 0, w.n / (BLOCKS * gridDim.x), blockIdx.x * BLOCKS, tag, tc, k, slot);
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
@@ -1070,6 +1083,10 @@ __global__ void __launch_bounds__(WG) k_scatter(Ws w, int level) {
                 const u32 j = q * WG + tid;
                 k[q] = j < m ? p[j] : 0ull;
             }
+            if (ROOT && H == 0 && w.raw_f64) {  // (uniform: the root reads the caller's array when nothing was stripped)
+#pragma unroll
+                for (int q = 0; q < ITEMS; ++q) k[q] = key_of(k[q]);
+            }
             // the keys' ranks inside their bins: independent returning adds, all in flight together
 #pragma unroll
             for (int q = 0; q < ITEMS; ++q) {
@@ -1315,6 +1332,10 @@ __global__ void __launch_bounds__(WG, 4) k_finish(Ws w) {  // (4 waves per SIMD 
         for (int q = 0; q < ITEMS; ++q) {
             const u32 j = q * WG + tid;
             pre[q] = j < m && (u64)f.off + j < (u64)w.n ? src[j] : 0ull;
+        }
+        if (f.src == SRC_IN && w.raw_f64) {  // (uniform)
+#pragma unroll
+            for (int q = 0; q < ITEMS; ++q) pre[q] = key_of(pre[q]);
         }
     };
     request(blockIdx.x);
@@ -1768,6 +1789,7 @@ int mc_sort_keys(const uint64_t *in, uint64_t n, uint64_t *out, void *workspace,
     w.B = (u64 *)(base + L.B);
     w.C = (u64 *)(base + L.C);
     w.n = (u32)n;
+    w.raw_f64 = (flags & MC_SORT_RAW_F64) ? 1u : 0u;
     w.region = L.region;
     w.regions = L.regions;
     w.cap_seg = L.cap_seg;

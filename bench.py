@@ -9,7 +9,9 @@ guess-number hot path on one GPU:
     [-> all-reduce of the per-test partial sums when world_size > 1 (in the step's order; --overlap-comm puts
         it, the guess numbers and the copy on a stream of their own beside the next step's sampling)]
     -> monotone guess numbers (mc_guess_numbers) -> the guess numbers to pinned host memory (8 B per test
-       password, inside the step; --d2h-all adds the order and the sorted scores)
+       password: three workgroups of the NEXT step's sampling launch move them while it samples, mc_sample_carry,
+       and the last step's follow the loop inside the timed region, so K steps deliver K result sets;
+       --d2h inline is the runtime's copy at the end of every step; --d2h-all adds the order and the sorted scores)
 
 Inputs (compiled tables, encoded test set) are resident in HBM before the timed region.
 Prints ONE JSON line on rank 0.  `python bench.py --gpus N --steps K --warmup W`; for N > 1
@@ -106,10 +108,12 @@ def main():
     ap.add_argument("--overlap-comm", action="store_true",
                     help="world > 1: all-reduce, guess numbers and copy on a stream of their own beside the next "
                          "step's sampling (the default keeps them in the step's own order)")
-    ap.add_argument("--d2h", choices=("overlap", "inline"), default="inline",
-                    help="copy of the guess numbers to the host: on the main stream inside the step (default: 1.56 ms "
-                         "a step, the same from run to run) or on a copy stream beside the next step (1.66 ms: the "
-                         "runtime copies with a kernel, which then competes with the sampler for the chip)")
+    ap.add_argument("--d2h", choices=("carry", "overlap", "inline"), default="carry",
+                    help="copy of the guess numbers to the host: `carry` (default): the NEXT step's sampling launch takes "
+                         "the copy along with three workgroups of its own (mc_sample_carry; the last step's copy "
+                         "follows the loop, inside the timed region): 0.98 ms a step; `inline`: the runtime's copy on the "
+                         "main stream inside the step (1.10 ms); `overlap`: on a copy stream beside the next step "
+                         "(slower still). With --second-stream or --overlap-comm `carry` means `inline`")
     ap.add_argument("--d2h-all", action="store_true",
                     help="copy the test set's order and sorted scores (12 B per password, the same every step) to the "
                          "host every step as well, not only the guess numbers")
@@ -172,12 +176,14 @@ def main():
     t_sorted = [torch.empty(T, dtype=torch.float64, device=dev) for _ in range(2)]
     t_order = [torch.empty(T, dtype=torch.int32, device=dev) for _ in range(2)]
     # (the guess numbers and the count of those that are exact share one buffer: ONE copy to the host a step)
-    g_both = [torch.empty(T + 1, dtype=torch.int64, device=dev) for _ in range(2)]
+    # (T + 1 words rounded up to whole 16 bytes: mc_sample_carry moves 16-byte words)
+    TB = (T + 2) & ~1
+    g_both = [torch.zeros(TB, dtype=torch.int64, device=dev) for _ in range(2)]
     g_rank = [b[:T] for b in g_both]
-    g_exact = [b[T:] for b in g_both]
-    h_both = [torch.empty(T + 1, dtype=torch.int64).pin_memory() for _ in range(2)]
+    g_exact = [b[T:T + 1] for b in g_both]
+    h_both = [torch.zeros(TB, dtype=torch.int64).pin_memory() for _ in range(2)]
     host = [{"rank": h_both[i][:T], "order": torch.empty(T, dtype=torch.int32).pin_memory(),
-             "ml2p": torch.empty(T, dtype=torch.float64).pin_memory(), "exact": h_both[i][T:]}
+             "ml2p": torch.empty(T, dtype=torch.float64).pin_memory(), "exact": h_both[i][T:T + 1]}
             for i in range(2)]
     ws_order = torch.empty(nv.lib.mc_order_workspace_bytes(T), dtype=torch.uint8, device=dev)
     ws_gn = torch.empty(nv.lib.mc_guess_numbers_workspace_bytes(T), dtype=torch.uint8, device=dev)
@@ -192,6 +198,13 @@ def main():
     main_stream = torch.cuda.current_stream(dev)
 
     rk_last = [None]
+    carry_mode = args.d2h == "carry" and comm is None and side is None
+    pending = [None]                                        # carry mode: the result set the next sampling launch takes along
+
+    def flush_carry():
+        if pending[0] is not None:                          # (the last step's guess numbers: the runtime's copy)
+            h_both[pending[0]].copy_(g_both[pending[0]], non_blocking=True)
+            pending[0] = None
 
     def step(it: int, timed: bool):
         """sample -> rank build -> [score -> order] -> queries -> guess numbers; the bracketed part runs on a
@@ -213,7 +226,11 @@ def main():
                 marks[4].record()
                 device_order(t_ml2p, out_sorted=t_sorted[slot], out_order=t_order[slot], workspace=ws_order)
                 marks[6].record()
-        dm.sample(N, seed, first_id=first, out=keys)
+        if carry_mode and pending[0] is not None:
+            dm.sample(N, seed, first_id=first, out=keys, carry=(g_both[pending[0]], h_both[pending[0]]))
+            pending[0] = None
+        else:
+            dm.sample(N, seed, first_id=first, out=keys)
         marks[1].record()
         for i, done in enumerate(reduced):                  # the previous step's all-reduce ran beside k_sample
             if done is not None:
@@ -273,6 +290,18 @@ def main():
                 reduced[slot] = marks[8]
             ready = marks[8]
         lane = copy if args.d2h == "overlap" else (comm if comm is not None else main_stream)
+        if carry_mode:
+            pending[0] = slot                               # (travels with the next step's sampling launch)
+            if args.d2h_all:
+                host[slot]["order"].copy_(t_order[slot], non_blocking=True)
+                host[slot]["ml2p"].copy_(t_sorted[slot], non_blocking=True)
+            if timed:
+                for k, (a_, b_) in (("sample", (0, 1)), ("rank", (1, 2)), ("score", (3, 4)), ("order", (4, 6)),
+                                    ("query", (5, 7))):
+                    ev[k].append((marks[a_], marks[b_]))
+                ev["guess_numbers"].append((marks[7] if world == 1 else marks[9], marks[8]))
+                ev["d2h"].append((ready, ready))
+            return
         if lane is main_stream or lane is comm:
             marks[10] = ready                               # (same stream as the guess numbers: nothing to wait for)
         else:
@@ -312,6 +341,7 @@ def main():
     t0 = time.perf_counter()
     for s in range(args.steps):
         step(args.warmup + s, True)
+    flush_carry()
     issued = time.perf_counter() - t0                       # the host's share: launching, not waiting
     fence()
     dt = time.perf_counter() - t0
@@ -350,6 +380,8 @@ def main():
         draws, probes = cnt["draws"] / args.steps, cnt["cdf_probes"] / args.steps
         indirect = cnt["indirect_draws"] / args.steps
         bytes_per_launch = draws * B_DRAW + indirect * B_INDIRECT + probes * B_PROBE + N * B_SAMPLE
+        if carry_mode:                                      # the launch also reads and writes the previous result set
+            bytes_per_launch += 2 * 8 * TB
         achieved = bytes_per_launch / (ms["sample"] * 1e-3) / 1e9
         rank_bytes = N * B_RANK
         gn_ms = ms["score"] + ms["order"] + ms["query"] + ms["guess_numbers"]
@@ -369,6 +401,8 @@ def main():
                        "samples_per_gpu": N, "test_pwds": T, "contexts": int(flat.info[nv.INFO_NCTX]),
                        "entries": int(flat.info[nv.INFO_NENT]), "table_bytes": int(flat.info[nv.INFO_DEVICE_BYTES])},
             "stage_ms": ms, "test_set_on_second_stream": side is not None,
+            "d2h": ("carry: each step's guess numbers travel with the next step's sampling launch (mc_sample_carry), "
+                    "the last step's after the loop, inside the timed region" if carry_mode else args.d2h),
             "host_issue_ms_per_step": issued / args.steps * 1e3,
             "sampling_only_per_s": N * world / (ms["sample"] * 1e-3),
             # the step as round 1 defined it (sample + rank build + score + bisection, nothing ordered, ranked or
@@ -378,7 +412,7 @@ def main():
             # copy of ranks/order/scores to the host (`d2h` in stage_ms) runs beside the next step
             "guess_numbers_per_s": T / (gn_ms * 1e-3),
             "guess_numbers_per_s_with_d2h_serial": T / ((gn_ms + ms["d2h"]) * 1e-3),
-            "d2h_bytes_per_step": (20 if args.d2h_all else 8) * T + 8, "guess_numbers_within_int64": exact / T,
+            "d2h_bytes_per_step": (20 if args.d2h_all else 8) * T + 8 * (TB - T), "guess_numbers_within_int64": exact / T,
             "draws_per_sample": draws / N, "indirect_draws_per_draw": indirect / max(draws, 1),
             "threshold_compares_per_draw": probes / max(draws, 1),
             # the longest single launch; HBM traffic from profiles/*pmc_hbm_traffic.json (rocprofv3 --pmc)

@@ -315,6 +315,18 @@ int mc_sample(mc_model *m, uint64_t first_id, uint64_t count, uint64_t seed, uin
               double *out_ml2p, uint32_t *out_len, uint32_t *out_draws, uint32_t *out_syms,
               uint32_t sym_stride, void *stream);
 
+/* mc_sample that takes a copy along: carry_bytes bytes from carry_src (device) to carry_dst (pinned host memory as
+ * a rule; any address the GPU can write) are moved by a few workgroups of the sampling launch itself, beside the
+ * sampling.  No counterpart in the reference: it is for pipelined callers (bench.py's step) whose previous
+ * results must reach the host while the next samples are drawn -- on this GPU a copy on a second stream slows the
+ * sampler by a quarter, a copy in the same stream waits for it; inside the launch it costs nothing.  Samples are
+ * those of mc_sample bit for bit.  Both addresses 16-byte aligned, carry_bytes a multiple of 16 (else MC_ERR_ARG);
+ * carry_bytes 0 is mc_sample; with count 0 or an MC_KIND_BPE model the copy is the runtime's, on `stream`.  The
+ * destination is complete when the launch is (stream order), not before. */
+int mc_sample_carry(mc_model *m, uint64_t first_id, uint64_t count, uint64_t seed, uint32_t max_draws,
+                    double *out_ml2p, uint32_t *out_len, uint32_t *out_draws, uint32_t *out_syms,
+                    uint32_t sym_stride, const void *carry_src, void *carry_dst, uint64_t carry_bytes, void *stream);
+
 /* ---- sampled strings, deduplicated on the GPU: what MonteCarlo.sample builds in `sampled_pwds`
  * (lib4mc/MonteCarloParent.py:40-45: string -> [ml2p of its first occurrence, occurrences], in
  * first-sampled order) and backwords_secondary_main.py:45-51 consumes.  Input: the symbol rows

@@ -87,7 +87,33 @@ struct SampleArgs {
     uint32_t hot_recs;  // draw-table records cached in LDS by k_sample
     float skew;         // k_sample: workgroup i of g owns the ids between count * f(i / g) and count * f((i + 1) / g),
                         // f(x) = (1 + skew) x - skew x^2: the first workgroups' ranges are (1 + skew) x the mean, the last (1 - skew) x
+    // mc_sample_carry: the first carry_groups workgroups of k_sample's grid sample nothing; they copy carry_n16
+    // 16-byte words from carry_src to carry_dst (pinned host memory as a rule) while the others sample
+    const uint4 *carry_src;
+    uint4 *carry_dst;
+    unsigned long long carry_n16;
+    uint32_t carry_groups;
 };
+
+// The copy mc_sample_carry takes along: `groups` workgroups of 256 lanes move n16 16-byte words, eight loads of a
+// lane in flight before their stores: ~15 GB/s a workgroup.  The pace is meant: 8 MB pushed over PCIe at the link's
+// full rate (8 workgroups, 0.18 ms) slowed the sampling beside it from 0.378 to 0.472 ms, at 3 workgroups (0.2 ms) to
+// 0.41 ms -- and 0.03 ms of that is the price of ANY workgroup that outlives the first generation of the grid, even
+// one that only sleeps, wherever it sits in the grid (scripts/carry_probe.py)
+__device__ __forceinline__ void carry_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, unsigned long long n16,
+                                           unsigned int group, unsigned int groups) {
+    constexpr int U = 8;
+    const unsigned long long stride = (unsigned long long)groups * 256u;
+    unsigned long long i = (unsigned long long)group * 256u + threadIdx.x;
+    for (; i + (U - 1) * stride < n16; i += U * stride) {
+        uint4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) dst[i + u * stride] = v[u];
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
 
 constexpr uint32_t PH_M0 = 0xD2511F53u, PH_M1 = 0xCD9E8D57u, PH_W0 = 0x9E3779B9u, PH_W1 = 0xBB67AE85u;
 
@@ -141,6 +167,12 @@ __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
     // first) lives in LDS: a.hot_recs records, loaded once per workgroup
     extern __shared__ __align__(16) unsigned char hot_raw[];
     DrawRec *hot = (DrawRec *)hot_raw;
+    if (blockIdx.x < a.carry_groups) {  // (whole workgroups, before any barrier: mc_sample_carry's copy)
+        carry_copy(a.carry_src, a.carry_dst, a.carry_n16, blockIdx.x, a.carry_groups);
+        return;
+    }
+    const unsigned int bid = blockIdx.x - a.carry_groups;
+    const unsigned int gdim = gridDim.x - a.carry_groups;  // the sampling grid
     __shared__ unsigned int blk_cnt[5];
     __shared__ unsigned int cursor;
     // finished keys wait here until their 128-byte line is whole (see "finished strings" below)
@@ -153,16 +185,16 @@ __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
     unsigned long long b0, b1;
     if (a.skew > 0.0f) {
         auto bound = [&](unsigned int i) -> unsigned long long {
-            if (i >= gridDim.x) return a.count;
-            const double x = (double)i / (double)gridDim.x;
+            if (i >= gdim) return a.count;
+            const double x = (double)i / (double)gdim;
             const unsigned long long v = (unsigned long long)((double)a.count * ((1.0 + (double)a.skew) * x - (double)a.skew * x * x));
             return min(a.count, v & ~(unsigned long long)(LINE_KEYS - 1));
         };
-        b0 = bound(blockIdx.x);
-        b1 = bound(blockIdx.x + 1);
+        b0 = bound(bid);
+        b1 = bound(bid + 1);
     } else {
-        const unsigned long long per = ((a.count + gridDim.x - 1) / gridDim.x + (LINE_KEYS - 1)) & ~(unsigned long long)(LINE_KEYS - 1);
-        b0 = min(a.count, (unsigned long long)blockIdx.x * per);
+        const unsigned long long per = ((a.count + gdim - 1) / gdim + (LINE_KEYS - 1)) & ~(unsigned long long)(LINE_KEYS - 1);
+        b0 = min(a.count, (unsigned long long)bid * per);
         b1 = min(a.count, b0 + per);
     }
     const unsigned int nblk = (unsigned int)(b1 - b0);
@@ -1121,6 +1153,9 @@ static int launch_sample(mc_model *m, bool inject, const SampleArgs &a_in, hipSt
     }
     SampleArgs a = a_in;
     a.hot_recs = 0;
+    const unsigned long long carry_n16 = a_in.carry_n16;
+    a.carry_n16 = 0;  // (k_sample_bpe carries nothing: its caller copies)
+    a.carry_groups = 0;
     if (m->dev.kind == MC_KIND_BPE) {
         unsigned long long want = (a.count + 255) / 256, cap = (unsigned long long)m->n_cu * 16;
         dim3 g((unsigned)(want < cap ? want : cap)), b(256);
@@ -1161,6 +1196,14 @@ static int launch_sample(mc_model *m, bool inject, const SampleArgs &a_in, hipSt
     unsigned long long cap = (unsigned long long)m->n_cu * (env_wg > 0 ? env_wg : 14);
     unsigned long long grid = want < cap ? want : cap;
     while ((a.count + grid - 1) / grid > 0x7FFFFFFFull) grid *= 2;
+    if (carry_n16) {
+        // one copy workgroup per 2.75 MiB (8 MB: 3 workgroups, 0.2 ms beside 0.38 ms of sampling), at most 32
+        static const int env_cg = getenv("MC_CARRY_GROUPS") ? atoi(getenv("MC_CARRY_GROUPS")) : 0;
+        const unsigned long long by_size = (carry_n16 * 16 + (11ull << 18) - 1) / (11ull << 18);
+        a.carry_n16 = carry_n16;
+        a.carry_groups = (uint32_t)(env_cg > 0 ? (env_cg > 256 ? 256 : env_cg) : by_size > 32 ? 32 : by_size);
+        grid += a.carry_groups;
+    }
     dim3 g((unsigned)grid), b(256);
     if (inject) {
         if (m->multichar) hipLaunchKernelGGL((k_sample<true, true, 1>), g, b, lds, s, m->dev, a);
@@ -1186,6 +1229,35 @@ extern "C" int mc_sample(mc_model *m, uint64_t first_id, uint64_t count, uint64_
     }
     SampleArgs a{first_id, count, seed, nullptr, out_ml2p, out_len, out_draws, out_syms, max_draws, sym_stride, 0};
     return launch_sample(m, false, a, (hipStream_t)stream);
+}
+
+extern "C" int mc_sample_carry(mc_model *m, uint64_t first_id, uint64_t count, uint64_t seed, uint32_t max_draws,
+                               double *out_ml2p, uint32_t *out_len, uint32_t *out_draws, uint32_t *out_syms,
+                               uint32_t sym_stride, const void *carry_src, void *carry_dst, uint64_t carry_bytes,
+                               void *stream) {
+    if (!m || (count && !out_ml2p) || max_draws == 0 || (out_syms && sym_stride == 0)) {
+        mc_set_error("mc_sample_carry: bad argument");
+        return MC_ERR_ARG;
+    }
+    if (carry_bytes && (!carry_src || !carry_dst || (carry_bytes & 15) || ((uintptr_t)carry_src & 15) ||
+                        ((uintptr_t)carry_dst & 15))) {
+        mc_set_error("mc_sample_carry: the copy taken along needs two 16-byte aligned addresses and a multiple of 16 "
+                     "bytes (got %llu bytes)", (unsigned long long)carry_bytes);
+        return MC_ERR_ARG;
+    }
+    SampleArgs a{first_id, count, seed, nullptr, out_ml2p, out_len, out_draws, out_syms, max_draws, sym_stride, 0};
+    const bool in_kernel = carry_bytes && count && m->dev.kind != MC_KIND_BPE && m->dev.start_state != MC_NONE;
+    if (in_kernel) {
+        a.carry_src = (const uint4 *)carry_src;
+        a.carry_dst = (uint4 *)carry_dst;
+        a.carry_n16 = carry_bytes / 16;
+    }
+    const int rc = launch_sample(m, false, a, (hipStream_t)stream);
+    if (rc != MC_OK) return rc;
+    // (nothing to sample beside, or a BPE model, whose sampler has no such workgroups: the runtime's copy)
+    if (carry_bytes && !in_kernel)
+        HIP_TRY(hipMemcpyAsync(carry_dst, carry_src, carry_bytes, hipMemcpyDefault, (hipStream_t)stream));
+    return MC_OK;
 }
 
 extern "C" int mc_sample_injected(mc_model *m, uint64_t count, const double *uniforms, uint32_t draws_per_sample,

@@ -57,14 +57,25 @@ class DeviceModel:
         return out
 
     def sample(self, count: int, seed: int, first_id: int = 0, max_draws: int = DEFAULT_MAX_DRAWS,
-               want_len: bool = False, want_draws: bool = False, sym_stride: int = 0, out: torch.Tensor = None):
-        """Launch the sampling kernel; returns dict(ml2p=, len=, draws=, syms=) of device tensors."""
+               want_len: bool = False, want_draws: bool = False, sym_stride: int = 0, out: torch.Tensor = None,
+               carry=None):
+        """Launch the sampling kernel; returns dict(ml2p=, len=, draws=, syms=) of device tensors.
+        ``carry=(src, dst)``: the launch also copies the device tensor ``src`` into ``dst`` (a pinned host tensor
+        as a rule) beside the sampling (mc_sample_carry); ``dst`` is complete when the launch is."""
         with torch.cuda.device(self.tdev):
             ml2p = out if out is not None else torch.empty(count, dtype=torch.float64, device=self.tdev)
             assert ml2p.numel() >= count and ml2p.dtype == torch.float64 and ml2p.is_contiguous()
             ln = torch.empty(count, dtype=torch.int32, device=self.tdev) if (want_len or sym_stride) else None
             dr = torch.empty(count, dtype=torch.int32, device=self.tdev) if want_draws else None
             sy = torch.zeros((count, sym_stride), dtype=torch.int32, device=self.tdev) if sym_stride else None
+            if carry is not None:
+                src, dst = carry
+                nbytes = src.numel() * src.element_size()
+                assert src.is_contiguous() and dst.is_contiguous() and dst.numel() * dst.element_size() == nbytes
+                nv.check(nv.lib.mc_sample_carry(self._h, first_id, count, seed & 0xFFFFFFFFFFFFFFFF, max_draws,
+                                                _vp(ml2p), _vp(ln), _vp(dr), _vp(sy), sym_stride, _vp(src), _vp(dst),
+                                                nbytes, self._stream()))
+                return {"ml2p": ml2p, "len": ln, "draws": dr, "syms": sy}
             nv.check(nv.lib.mc_sample(self._h, first_id, count, seed & 0xFFFFFFFFFFFFFFFF, max_draws, _vp(ml2p),
                                       _vp(ln), _vp(dr), _vp(sy), sym_stride, self._stream()))
         return {"ml2p": ml2p, "len": ln, "draws": dr, "syms": sy}

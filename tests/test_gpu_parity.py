@@ -303,6 +303,33 @@ def test_launch_geometry_does_not_change_results(big_model):
     assert torch.equal(a.view(torch.int64), b.view(torch.int64))
 
 
+def test_sample_carry_copies_beside_the_same_samples(big_model):
+    """mc_sample_carry (include/mi355mc.h): the samples are mc_sample's bit for bit and the copy taken along arrives
+    whole -- in pinned host memory and in device memory, sizes around the copy workgroups' strides, size 0, a count
+    of 0 (the runtime's copy then); misaligned sizes are refused before anything is launched."""
+    m, _ = big_model
+    dm = m._dev
+    want = dm.sample(70000, 11, first_id=5)["ml2p"]
+    g = torch.Generator().manual_seed(5)
+    for words in (2, 8 * 256 * 2 - 2, 8 * 256 * 2 * 8 * 3 + 2, 1_000_002):           # int64 words, 16 bytes a pair
+        src = torch.randint(-2 ** 62, 2 ** 62, (words,), generator=g, dtype=torch.int64).cuda()
+        for dst in (torch.zeros(words, dtype=torch.int64).pin_memory(), torch.zeros(words, dtype=torch.int64, device="cuda")):
+            got = dm.sample(70000, 11, first_id=5, carry=(src, dst))["ml2p"]
+            torch.cuda.synchronize()
+            assert torch.equal(got.view(torch.int64), want.view(torch.int64))
+            assert torch.equal(dst.cpu(), src.cpu())
+    src = torch.arange(64, dtype=torch.int64).cuda()
+    dst = torch.zeros(64, dtype=torch.int64).pin_memory()
+    dm.sample(0, 11, carry=(src, dst))
+    torch.cuda.synchronize()
+    assert torch.equal(dst, src.cpu())
+    dm.check()
+    with pytest.raises(RuntimeError, match="multiple of 16"):
+        dm.sample(100, 11, carry=(src[:3], dst[:3]))
+    with pytest.raises(RuntimeError, match="aligned"):
+        dm.sample(100, 11, carry=(src[1:5], dst[1:5]))
+
+
 def test_sampled_pwds_dedup_on_gpu(big_model):
     """MonteCarlo.sample(size, sampled_pwds): the dict built from the GPU-side dedup (one row per
     distinct string reaches the host) equals the one built by decoding every sample, in content and

@@ -13,6 +13,10 @@ guess-number hot path on one GPU:
        and the last step's follow the loop inside the timed region, so K steps deliver K result sets;
        --d2h inline is the runtime's copy at the end of every step; --d2h-all adds the order and the sorted scores)
 
+Scoring the test set and putting it in order do not depend on the samples: they run on a second stream beside
+sampling and the rank build (--serial: one stream, in the order above), and the sampler launches 7 workgroups a
+CU, which leaves every CU a slot for them (mc_sample_tune).
+
 Inputs (compiled tables, encoded test set) are resident in HBM before the timed region.
 Prints ONE JSON line on rank 0.  `python bench.py --gpus N --steps K --warmup W`; for N > 1
 launch through torch.distributed.run (one rank per GPU, weak scaling: every GPU draws N).
@@ -100,11 +104,15 @@ def main():
     ap.add_argument("--tests", type=int, default=1_000_000)
     ap.add_argument("--train-lines", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--second-stream", action="store_true",
-                    help="score and order the test set (they do not depend on the samples) on a second stream beside "
-                         "sampling and the rank build; measured slower than one stream (1.71 vs 1.56 ms a step: the "
-                         "sampler fills the chip, the small launches only wait longer)")
-    ap.add_argument("--serial", action="store_true", help=argparse.SUPPRESS)         # (the default)
+    ap.add_argument("--second-stream", action="store_true", help=argparse.SUPPRESS)  # (the default)
+    ap.add_argument("--serial", action="store_true",
+                    help="everything on one stream in the step's own order (0.98 ms a step). Default: the test set is "
+                         "scored and put in order -- neither depends on the samples -- on a second stream beside sampling "
+                         "and the rank build, and the sampler runs 7 workgroups a CU instead of 14, which leaves every "
+                         "CU a slot for those small launches (mc_sample_tune): 0.76 ms a step")
+    ap.add_argument("--sample-wg-per-cu", type=int, default=0,
+                    help="workgroups a CU of the sampling launch (default: 7 with the second stream, the library's 14 "
+                         "with --serial)")
     ap.add_argument("--overlap-comm", action="store_true",
                     help="world > 1: all-reduce, guess numbers and copy on a stream of their own beside the next "
                          "step's sampling (the default keeps them in the step's own order)")
@@ -113,7 +121,7 @@ def main():
                          "the copy along with three workgroups of its own (mc_sample_carry; the last step's copy "
                          "follows the loop, inside the timed region): 0.98 ms a step; `inline`: the runtime's copy on the "
                          "main stream inside the step (1.10 ms); `overlap`: on a copy stream beside the next step "
-                         "(slower still). With --second-stream or --overlap-comm `carry` means `inline`")
+                         "(slower still). With --overlap-comm `carry` means `inline`")
     ap.add_argument("--d2h-all", action="store_true",
                     help="copy the test set's order and sorted scores (12 B per password, the same every step) to the "
                          "host every step as well, not only the guess numbers")
@@ -194,11 +202,15 @@ def main():
     seed = 20250304
 
     ev = {k: [] for k in ("sample", "rank", "score", "order", "query", "guess_numbers", "d2h")}
-    side = torch.cuda.Stream(device=dev) if args.second_stream else None
+    side = None if args.serial else torch.cuda.Stream(device=dev)
+    if side is not None or args.sample_wg_per_cu:
+        # one generation of sampling workgroups that leaves each CU a free slot (scripts/side_compare.sh: 14 a CU
+        # 0.807 ms a step, 12 0.787, 10 0.796, 8 0.812, 7 0.759, 6 0.831)
+        dm.tune(wg_per_cu=args.sample_wg_per_cu or int(os.environ.get("MC_SAMPLE_WG_PER_CU", "7")))
     main_stream = torch.cuda.current_stream(dev)
 
     rk_last = [None]
-    carry_mode = args.d2h == "carry" and comm is None and side is None
+    carry_mode = args.d2h == "carry" and comm is None
     pending = [None]                                        # carry mode: the result set the next sampling launch takes along
 
     def flush_carry():
@@ -208,7 +220,8 @@ def main():
 
     def step(it: int, timed: bool):
         """sample -> rank build -> [score -> order] -> queries -> guess numbers; the bracketed part runs on a
-        second stream from the start of the step unless --serial, the copies to the host on a third."""
+        second stream from the start of the step unless --serial; the guess numbers reach the host with the
+        next step's sampling launch (--d2h)."""
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(12)]
         slot = it & 1
         first = first_id(it, world, rank, N)                # disjoint Philox sample ids per rank and step
@@ -401,6 +414,9 @@ def main():
                        "samples_per_gpu": N, "test_pwds": T, "contexts": int(flat.info[nv.INFO_NCTX]),
                        "entries": int(flat.info[nv.INFO_NENT]), "table_bytes": int(flat.info[nv.INFO_DEVICE_BYTES])},
             "stage_ms": ms, "test_set_on_second_stream": side is not None,
+            "stage_ms_note": ("score and order run on a second stream beside sample and rank (their times include "
+                              "waiting for free slots); the step is sample + rank + query + guess_numbers"
+                              if side is not None else "one stream: the step is the sum of the stages"),
             "d2h": ("carry: each step's guess numbers travel with the next step's sampling launch (mc_sample_carry), "
                     "the last step's after the loop, inside the timed region" if carry_mode else args.d2h),
             "host_issue_ms_per_step": issued / args.steps * 1e3,
@@ -410,8 +426,10 @@ def main():
             "round1_step_samples_per_s": N * world / ((ms["sample"] + ms["rank"] + ms["score"] + ms["query"]) * 1e-3),
             # score + stable order + bisection + monotone guess numbers (device time of those four stages); the
             # copy of ranks/order/scores to the host (`d2h` in stage_ms) runs beside the next step
-            "guess_numbers_per_s": T / (gn_ms * 1e-3),
-            "guess_numbers_per_s_with_d2h_serial": T / ((gn_ms + ms["d2h"]) * 1e-3),
+            # every step delivers T guess numbers to the host
+            "guess_numbers_per_s": T * world * args.steps / dt,
+            # (--serial only: T over the device time of score + order + query + guess numbers, one after the other)
+            "guess_numbers_stages_per_s": T / (gn_ms * 1e-3) if side is None else None,
             "d2h_bytes_per_step": (20 if args.d2h_all else 8) * T + 8 * (TB - T), "guess_numbers_within_int64": exact / T,
             "draws_per_sample": draws / N, "indirect_draws_per_draw": indirect / max(draws, 1),
             "threshold_compares_per_draw": probes / max(draws, 1),

@@ -1014,6 +1014,9 @@ struct mc_model {
     size_t arena_bytes;
     DevModel dev;
     bool multichar;
+    // mc_sample_tune: launch geometry of k_sample (0 / negative: the library's defaults)
+    int tune_wg_per_cu = 0, tune_hot_kb = -1;
+    float tune_skew = -1.0f;
 };
 
 extern "C" int mc_model_upload(const mc_table *t, int device, mc_model **out) {
@@ -1185,15 +1188,18 @@ static int launch_sample(mc_model *m, bool inject, const SampleArgs &a_in, hipSt
     static const int env_wg = getenv("MC_SAMPLE_WG_PER_CU") ? atoi(getenv("MC_SAMPLE_WG_PER_CU")) : 14;
     static const int env_hot = getenv("MC_SAMPLE_HOT_KB") ? atoi(getenv("MC_SAMPLE_HOT_KB")) : 15;
     const int nc = inject ? 1 : env_nc;
+    const int hot_kb = m->tune_hot_kb >= 0 ? m->tune_hot_kb : env_hot;
+    const int wg_per_cu = m->tune_wg_per_cu > 0 ? m->tune_wg_per_cu : env_wg;
     {
-        unsigned long long recs = (unsigned long long)(env_hot < 0 ? 0 : env_hot > 150 ? 150 : env_hot) * 1024 / 16;
+        unsigned long long recs = (unsigned long long)(hot_kb < 0 ? 0 : hot_kb > 150 ? 150 : hot_kb) * 1024 / 16;
         a.hot_recs = (uint32_t)(recs < m->n_draw ? recs : m->n_draw);
     }
     static const float env_skew = getenv("MC_SAMPLE_SKEW") ? (float)atof(getenv("MC_SAMPLE_SKEW")) : 0.55f;
-    a.skew = env_skew < 0.0f ? 0.0f : env_skew > 0.95f ? 0.95f : env_skew;
+    const float skew = m->tune_skew >= 0.0f ? m->tune_skew : env_skew;
+    a.skew = skew < 0.0f ? 0.0f : skew > 0.95f ? 0.95f : skew;
     const size_t lds = (size_t)a.hot_recs * sizeof(DrawRec);
     unsigned long long want = (a.count + 64ull * nc - 1) / (64ull * nc);
-    unsigned long long cap = (unsigned long long)m->n_cu * (env_wg > 0 ? env_wg : 14);
+    unsigned long long cap = (unsigned long long)m->n_cu * (wg_per_cu > 0 ? wg_per_cu : 14);
     unsigned long long grid = want < cap ? want : cap;
     while ((a.count + grid - 1) / grid > 0x7FFFFFFFull) grid *= 2;
     if (carry_n16) {
@@ -1217,6 +1223,17 @@ static int launch_sample(mc_model *m, bool inject, const SampleArgs &a_in, hipSt
         else hipLaunchKernelGGL((k_sample<false, false, 1>), g, b, lds, s, m->dev, a);
     }
     HIP_TRY(hipGetLastError());
+    return MC_OK;
+}
+
+extern "C" int mc_sample_tune(mc_model *m, int wg_per_cu, float skew, int hot_kb) {
+    if (!m || wg_per_cu > 64 || hot_kb > 150 || skew > 0.95f) {
+        mc_set_error("mc_sample_tune: null model, or more than 64 workgroups a CU, a skew above 0.95 or more than 150 KB");
+        return MC_ERR_ARG;
+    }
+    m->tune_wg_per_cu = wg_per_cu;
+    m->tune_skew = skew;
+    m->tune_hot_kb = hot_kb;
     return MC_OK;
 }
 

@@ -56,6 +56,10 @@ class DeviceModel:
         nv.check(rc)
         return out
 
+    def tune(self, wg_per_cu: int = 0, skew: float = -1.0, hot_kb: int = -1):
+        """Launch geometry of the sampling kernel (mc_sample_tune; never changes a sample); no arguments: defaults."""
+        nv.check(nv.lib.mc_sample_tune(self._h, wg_per_cu, skew, hot_kb))
+
     def sample(self, count: int, seed: int, first_id: int = 0, max_draws: int = DEFAULT_MAX_DRAWS,
                want_len: bool = False, want_draws: bool = False, sym_stride: int = 0, out: torch.Tensor = None,
                carry=None):

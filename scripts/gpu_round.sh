@@ -26,15 +26,15 @@ for s in $STEPS; do
       cat "$OUT/bench.json" ;;
     prof)
       timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o r -- \
-        python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_prof.json" 2> "$OUT/prof.err" \
+        python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline > "$OUT/bench_prof.json" 2> "$OUT/prof.err" \
         || { rc=$?; tail -20 "$OUT/prof.err"; die prof $rc; }
       find "$OUT/trace" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats.csv" \;
       rm -f $(find "$OUT/trace" -name '*kernel_trace.csv')   # large; the stats are what we keep
       head -8 "$OUT/kernel_stats.csv" | cut -c1-160 ;;
-    pmc)
+    pmc)   # (--serial: the summary tells the three sorts of a step apart by the order of the dispatches)
       for c in FETCH_SIZE WRITE_SIZE; do
         timeout -s KILL 240 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_$c" -o r -- \
-          python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_$c.json" 2> "$OUT/pmc_$c.err" \
+          python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --serial --sample-wg-per-cu 7 > "$OUT/pmc_$c.json" 2> "$OUT/pmc_$c.err" \
           || { rc=$?; tail -20 "$OUT/pmc_$c.err"; die pmc_$c $rc; }
       done
       python3 scripts/pmc_summary.py "$OUT" > "$OUT/pmc_summary.json" && cat "$OUT/pmc_summary.json" ;;
@@ -44,7 +44,7 @@ for s in $STEPS; do
       for grp in "${GROUPS_[@]}"; do
         i=$((i+1))
         timeout -s KILL 240 rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmcx_$i" -o r -- \
-          python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmcx_$i.json" 2> "$OUT/pmcx_$i.err" \
+          python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --serial --sample-wg-per-cu 7 > "$OUT/pmcx_$i.json" 2> "$OUT/pmcx_$i.err" \
           || { rc=$?; tail -20 "$OUT/pmcx_$i.err"; die pmcx_$i $rc; }
       done
       python3 scripts/pmcx_summary.py "$OUT" | tee "$OUT/pmcx_summary.txt" ;;

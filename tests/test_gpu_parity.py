@@ -301,6 +301,20 @@ def test_launch_geometry_does_not_change_results(big_model):
     b = torch.cat([m._dev.sample(20000, 7, first_id=1000)["ml2p"], m._dev.sample(30000, 7, first_id=21000)["ml2p"]])
     m._dev.check()
     assert torch.equal(a.view(torch.int64), b.view(torch.int64))
+    # mc_sample_tune: workgroups per CU, skew of their ranges, KB of the draw table in LDS
+    want = m._dev.sample(1_200_007, 9, first_id=2 ** 33, want_len=True, want_draws=True, sym_stride=12)
+    try:
+        for geometry in ((7, 0.55, 15), (7, 0.0, 0), (3, 0.9, 40), (20, 0.25, 8), (1, -1.0, -1)):
+            m._dev.tune(*geometry)
+            got = m._dev.sample(1_200_007, 9, first_id=2 ** 33, want_len=True, want_draws=True, sym_stride=12)
+            assert torch.equal(got["ml2p"].view(torch.int64), want["ml2p"].view(torch.int64)), geometry
+            for k in ("len", "draws", "syms"):
+                assert torch.equal(got[k], want[k]), (geometry, k)
+        with pytest.raises(RuntimeError, match="mc_sample_tune"):
+            m._dev.tune(65)
+    finally:
+        m._dev.tune()
+    m._dev.check()
 
 
 def test_sample_carry_copies_beside_the_same_samples(big_model):

@@ -389,6 +389,20 @@ def main():
     assert np.array_equal(t_ml2p.cpu().numpy()[last["order"].numpy().view(np.uint32)], last["ml2p"].numpy())
     sort_info = rk_last[0].check()
 
+    # the sampling launch with the GPU to itself (the library's own geometry, nothing carried, no second stream):
+    # 50 launches after the timed region, for the roofline line beside the in-step figure
+    dm.tune()
+    for _ in range(5):
+        dm.sample(N, seed, first_id=0, out=keys)
+    a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a0.record()
+    for i in range(50):
+        dm.sample(N, seed, first_id=i * N, out=keys)
+    a1.record()
+    torch.cuda.synchronize()
+    alone_ms = a0.elapsed_time(a1) / 50
+    dm.check()
+
     if rank == 0:
         draws, probes = cnt["draws"] / args.steps, cnt["cdf_probes"] / args.steps
         indirect = cnt["indirect_draws"] / args.steps
@@ -437,7 +451,15 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_sample", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC.get("k_sample"),
                          "traffic_source": TRAFFIC_SOURCE,
-                         "bytes_per_launch": bytes_per_launch, "kernel_ms": ms["sample"]},
+                         "bytes_per_launch": bytes_per_launch, "kernel_ms": ms["sample"],
+                         "note": "timed inside the step: the copy workgroups of mc_sample_carry and the second "
+                                 "stream's launches share the GPU with it" if side is not None else "",
+                         "alone": {"kernel_ms": alone_ms, "achieved": (bytes_per_launch - (2 * 8 * TB if carry_mode else 0))
+                                   / (alone_ms * 1e-3) / 1e9,
+                                   "frac": (bytes_per_launch - (2 * 8 * TB if carry_mode else 0)) / (alone_ms * 1e-3) / 1e9
+                                   / HBM_PEAK_GBS,
+                                   "what": "50 launches of the same 1e7 samples after the timed region, GPU to itself, "
+                                           "the library's default geometry (14 workgroups a CU), nothing carried"}},
             # the rank build as a whole (csrc/mc_sort.hip's launches + weight sums + positions, timed together)
             # against the 40 B/key a sort-and-scan cannot do without
             "roofline_rank_build": {"bound": "hbm", "kernel": "mc_rank_build (k_sniff, k_strip, k_scatter, k_count, "

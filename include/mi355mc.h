@@ -329,7 +329,7 @@ int mc_sample_carry(mc_model *m, uint64_t first_id, uint64_t count, uint64_t see
 
 /* Launch geometry of the sampling kernel for this model (no counterpart in the reference; samples never depend on
  * it): workgroups per compute unit (default 14, of which 8 are resident: best when the sampler has the GPU to
- * itself; 7 leaves every compute unit a free slot for the kernels of a second stream -- bench.py scores and orders
+ * itself, and 7 for mc_sample_carry; 7 leaves every compute unit a free slot for the kernels of a second stream -- bench.py scores and orders
  * the test set there), the skew of the workgroups' id ranges (default 0.55: ranges shrink linearly from 1.55 x to
  * 0.45 x the mean) and the KB of the draw table's head kept in LDS (default 15).  wg_per_cu <= 0, skew < 0 or
  * hot_kb < 0 put the default back (the MC_SAMPLE_* environment variables set the defaults).  Not synchronised

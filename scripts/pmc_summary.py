@@ -8,7 +8,7 @@ gathers are uncalibrated by the guide, so both raw and corrected figures are kep
 
 The sort's kernels run three times a step (mc_rank_build, and twice inside mc_order_keys): the per-stage totals
 follow the dispatches in order (k_sample opens a step, k_positions closes the rank build, k_order_prep .. k_order_out
-bracket the order).  `_per_step` also carries the digest of the native sources the numbers were measured on.
+bracket the order; since r02-m, which dropped k_order_prep, the order starts with the first kernel after k_score).  `_per_step` also carries the digest of the native sources the numbers were measured on.
 """
 import csv
 import glob
@@ -47,14 +47,21 @@ def per_stage(rs):
     """kilobytes per stage, summed over the steps seen, and the number of steps"""
     tot = defaultdict(float)
     stage, steps = None, 0
+    # the sampling launches after the timed region (bench.py's roofline.alone) are no steps: cut where two of our
+    # kernels in a row are k_sample
+    ours = [i for i, (_, name, _) in enumerate(rs) if not name.startswith("at::") and "rocclr" not in name]
+    for a, b in zip(ours, ours[1:]):
+        if rs[a][1].split("<")[0] == "k_sample" and rs[b][1].split("<")[0] == "k_sample":
+            rs = rs[:a]
+            break
     for _, name, v in rs:
         base = name.split("<")[0]
         if base == "k_sample":
             stage, steps = "k_sample", steps + 1
         elif base.startswith("k_score"):
             stage = "k_score"
-        elif base == "k_order_prep":
-            stage = "mc_order_keys"
+        elif stage == "k_score" and not base.startswith("k_score"):
+            stage = "mc_order_keys"          # (the first kernel after the scoring: the order's key sort)
         elif base == "k_query":
             stage = "k_query"
         elif base.startswith("k_gn_"):

@@ -402,14 +402,26 @@ int mc_score_bpe(mc_model *m, const uint32_t *cps, const uint8_t *cls, const uin
  * Failure is loud: if a table overflows or a count does not match its keys (the caller overwrote keys_in
  * while the build ran), nothing is written outside the buffers, `positions` is filled with NaN and
  * mc_rank_check reports it.
+ *
+ * The workspace also carries a hint from one build to the next: the list of heavily repeated values the last
+ * build of n keys found there is taken again instead of being searched for (keys from one source repeat the same
+ * values; any list gives a correct sort, a stale one only a slower one); the search runs again when the tail it
+ * leaves has grown by a quarter or is more than three quarters of the keys, every 64th build, and whenever the workspace holds no such list.  Results never
+ * depend on it; MC_SORT_REUSE=0 in the environment turns it off.
  */
 size_t mc_rank_workspace_bytes(uint64_t n);
 int mc_rank_build(const double *keys_in, uint64_t n, uint64_t n_global, double *keys_sorted, double *positions,
                   void *workspace, size_t workspace_bytes, void *stream);
 
+/* Makes a workspace of mc_rank_build or mc_order_keys for n keys forget the list of heavy values it may hold (the
+ * next call searches for them): for a caller that hands out workspaces from a pool and wants every call to behave
+ * as the first, as the host classes do for the workspaces they allocate themselves.  No counterpart in the reference. */
+int mc_workspace_forget(void *workspace, uint64_t n, void *stream);
+
 /* Synchronises `stream` and reads the status of the last mc_rank_build that used `workspace` for n keys:
  * MC_OK, or MC_ERR_WORKSPACE when the build failed on the device (positions are NaN then).  info (may be
- * NULL) receives {error word, heavy values found, tail keys, radix levels used, finish tiles, segments, 0, 0}.
+ * NULL) receives {error word, heavy values found, tail keys, radix levels used, finish tiles, segments, builds the
+ * list of heavy values has served since it was searched for, 0}.
  * No counterpart in the reference (its list.sort() cannot fail). */
 int mc_rank_check(const void *workspace, uint64_t n, void *stream, uint64_t info[8]);
 /* Test hook: while on, every mc_rank_build takes its device-side failure path (tables "overflow" at once). */

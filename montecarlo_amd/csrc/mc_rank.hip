@@ -330,6 +330,14 @@ extern "C" int mc_rank_build(const double *keys_in, uint64_t n, uint64_t n_globa
     return MC_OK;
 }
 
+extern "C" int mc_workspace_forget(void *workspace, uint64_t n, void *stream) {
+    if (!workspace || n == 0 || n >= (1ull << 32)) {
+        mc_set_error("mc_workspace_forget: null workspace or a key count outside 1 .. 2^32 - 1");
+        return MC_ERR_ARG;
+    }
+    return mc_sort_forget(workspace, n, (hipStream_t)stream);
+}
+
 extern "C" int mc_rank_check(const void *workspace, uint64_t n, void *stream, uint64_t info[8]) {
     uint64_t local[8] = {0};
     if (!workspace || n == 0) {

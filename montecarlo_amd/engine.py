@@ -202,6 +202,11 @@ class DeviceRank:
             ws = workspace if workspace is not None else torch.empty(need, dtype=torch.uint8, device=self.tdev)
             self.keys_sorted = keys_sorted if keys_sorted is not None else torch.empty_like(keys)
             self.positions = positions if positions is not None else torch.empty_like(keys)
+            stream = C.c_void_p(torch.cuda.current_stream(self.tdev).cuda_stream)
+            if workspace is None and self.n:
+                # (a caller's workspace carries the list of heavy values from one build to the next, include/mi355mc.h;
+                # memory fresh from the allocator may hold anything, another build's list included: start clean)
+                nv.check(nv.lib.mc_workspace_forget(_vp(ws), self.n, stream))
             nv.check(nv.lib.mc_rank_build(_vp(keys), self.n, self.n_global, _vp(self.keys_sorted),
                                           _vp(self.positions), _vp(ws), ws.numel(),
                                           C.c_void_p(torch.cuda.current_stream(self.tdev).cuda_stream)))
@@ -214,7 +219,7 @@ class DeviceRank:
         with torch.cuda.device(self.tdev):
             rc = nv.lib.mc_rank_check(_vp(self._ws), self.n,
                                       C.c_void_p(torch.cuda.current_stream(self.tdev).cuda_stream), info)
-        out = dict(zip(("error", "heavy_values", "tail_keys", "levels", "finish_tiles", "segments"), list(info)))
+        out = dict(zip(("error", "heavy_values", "tail_keys", "levels", "finish_tiles", "segments", "list_age"), list(info)))
         nv.check(rc)
         return out
 
@@ -245,6 +250,8 @@ def device_order(x: torch.Tensor, out_sorted: torch.Tensor = None, out_order: to
         if t:
             ws = workspace if workspace is not None else torch.empty(nv.lib.mc_order_workspace_bytes(t),
                                                                      dtype=torch.uint8, device=x.device)
+            if workspace is None:                            # (no list of another sort's heavy values: see DeviceRank)
+                nv.check(nv.lib.mc_workspace_forget(_vp(ws), t, C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
             nv.check(nv.lib.mc_order_keys(_vp(x), t, _vp(srt), _vp(order), _vp(ws), ws.numel(),
                                           C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
             if workspace is None:

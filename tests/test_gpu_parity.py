@@ -18,7 +18,7 @@ import pytest
 import torch
 
 from conftest import fh, golden, golden_lines, hx  # noqa: F401
-from montecarlo_amd import synth
+from montecarlo_amd import _native as nv, synth
 from montecarlo_amd.backwords.backwords_secondary_trainer import backwords_counter as secondary_counter
 from montecarlo_amd.backwords_secondary_simulator import BackWordsSecondaryMonteCarlo
 from montecarlo_amd.backwords_simulator import BackWordsMonteCarlo
@@ -713,6 +713,47 @@ def test_rank_key_distributions():
         if name != "all bit patterns":                       # (there the weights overflow: 2 ** 1e308)
             ref = torch.cumsum(torch.exp2(srt - np.log2(n)), 0)
             assert float(((rk.positions - ref).abs() / ref).max()) < REL, name
+
+
+def test_rank_build_takes_the_last_builds_heavy_values_again(big_model):
+    """The workspace hands the list of heavy values from one build to the next (include/mi355mc.h, mc_rank_build):
+    builds of fresh samples from one model reuse it (age 1, 2, ...) and are searched for again after 63 builds; keys
+    from another source in the same workspace are sorted correctly with the stale list and bring a new search at
+    the build after; a workspace full of noise is no list.  Sorted keys equal torch.sort every time, positions are
+    those of a build that searched (bit for bit: a fresh workspace)."""
+    m, _ = big_model
+    n = 400_003
+    ws = torch.empty(nv.lib.mc_rank_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    ws.random_(0, 256)                                       # noise: must not pass for a list
+    g = torch.Generator(device="cuda").manual_seed(1)
+
+    def build(keys, workspace):
+        rk = DeviceRank(keys, workspace=workspace)
+        info = rk.check()
+        assert torch.equal(rk.keys_sorted, torch.sort(keys)[0])
+        return rk, info
+
+    ages = []
+    for it in range(67):
+        keys = m._dev.sample(n, 100 + it)["ml2p"]
+        rk, info = build(keys, ws)
+        ages.append(info["list_age"])
+        if it in (0, 1, 5, 64):
+            fresh = torch.empty_like(ws).zero_()
+            rk2, info2 = build(keys, fresh)
+            assert info2["list_age"] == 0
+            assert torch.equal(rk.positions.view(torch.int64), rk2.positions.view(torch.int64))
+    assert ages[:4] == [0, 1, 2, 3] and ages[63] == 63 and ages[64] == 0 and ages[65] == 1, ages
+    # another source: uniform keys have no heavy values at all
+    other = torch.rand(n, generator=g, device="cuda", dtype=torch.float64) * 40
+    _, a = build(other, ws)
+    _, b = build(other, ws)
+    assert a["list_age"] == 3 and a["tail_keys"] == n and b["list_age"] == 0, (a, b)
+    # and back: the search runs (the uniform keys left no list), then serves again
+    keys = m._dev.sample(n, 7)["ml2p"]
+    _, c = build(keys, ws)
+    _, d = build(m._dev.sample(n, 8)["ml2p"], ws)
+    assert c["list_age"] == 0 and d["list_age"] == 1 and d["heavy_values"] == c["heavy_values"], (c, d)
 
 
 def test_rank_large_search_for_heavy_values(big_model):

@@ -437,7 +437,9 @@ def main():
             "sampling_only_per_s": N * world / (ms["sample"] * 1e-3),
             # the step as round 1 defined it (sample + rank build + score + bisection, nothing ordered, ranked or
             # copied), from the same launches' stage times: the figure to hold against round 1's 9.6e9
-            "round1_step_samples_per_s": N * world / ((ms["sample"] + ms["rank"] + ms["score"] + ms["query"]) * 1e-3),
+            # (--serial only: on two streams the scoring's stage time is mostly waiting beside the sampler)
+            "round1_step_samples_per_s": (N * world / ((ms["sample"] + ms["rank"] + ms["score"] + ms["query"]) * 1e-3)
+                                          if side is None else None),
             # score + stable order + bisection + monotone guess numbers (device time of those four stages); the
             # copy of ranks/order/scores to the host (`d2h` in stage_ms) runs beside the next step
             # every step delivers T guess numbers to the host

@@ -33,7 +33,8 @@ typedef enum mc_status {
     MC_ERR_HIP = -3,          /* a HIP runtime call failed */
     MC_ERR_NOMEM = -4,
     MC_ERR_DIVERGED = -5,     /* a sample hit max_draws without reaching the end symbol */
-    MC_ERR_WORKSPACE = -6     /* workspace too small */
+    MC_ERR_WORKSPACE = -6,    /* workspace too small, or a build failed on the device (mc_rank_check) */
+    MC_ERR_UNSUITED = -7      /* mc_rank_runs_check: the keys do not suit the run index; use mc_rank_build */
 } mc_status;
 
 /* Context rule of the model (which `_get_prefix` it restates). */
@@ -446,6 +447,50 @@ void mc_rank_debug_search(int mode);
 uint64_t mc_rank_noalloc_max_keys(void);
 int mc_rank_build_noalloc(const double *keys_in, uint64_t n, uint64_t n_global, double *keys_sorted,
                           double *positions, void *stream);
+
+/* ---- rank estimation from the runs of equal keys ---------------------------------------------------------
+ * MonteCarloLib.__init__ + ml2p2rank (lib4mc/MonteCarloLib.py:10-32) again, built from what a query reads.
+ * `bisect_right(sorted, x)` (:31) always lands on the END of a run of equal keys, so of the n sorted keys and n
+ * positions the reference materialises (:11-27) a query reads one entry per DISTINCT value, and sampled -log2 p
+ * repeat heavily (1e7 samples of the headline model hold 170,340 distinct values).  The index is, per distinct
+ * value v in ascending order (D of them):
+ *     vals[d] = v,   cum_count[d] = #{keys <= v},   cum_pos[d] = sum of 2^(key - log2 n_global) over those keys
+ * = positions[cum_count[d] - 1] of mc_rank_build up to the order of the additions (compare at 1e-9 relative;
+ * cum_count and vals are exact).  The sorted array is never written: ONE read of the keys (copies of the values
+ * that repeat most are counted in LDS, the rest is ordered by value range batch by batch and counted range by
+ * range in LDS; csrc/mc_runs.hip), four launches, no workgroup ever waits for another one.
+ *   vals / cum_count / cum_pos   outputs (device), `capacity` >= mc_rank_runs_capacity(n) entries each
+ *   info                         output (device uint64[8]): {D, error word, keys counted, heavy values, tail keys,
+ *                                builds the list of heavy values has served, 0, 0}; the query reads D from it, so
+ *                                nothing comes back to the host between build and query
+ * Keys: non-negative doubles (as mc_rank_build), n <= mc_rank_runs_max_keys() = 2^26.  Keys that do not repeat
+ * (more than 2048 distinct values in one of the 1024 equal parts of the value range: uniform random numbers) do
+ * not suit the index: the build then marks it failed (error word set, D = 0, every query answers NaN) and
+ * mc_rank_runs_check returns MC_ERR_UNSUITED -- the caller builds with mc_rank_build instead, which sorts anything
+ * (montecarlo_amd.engine.DeviceRank does).  The workspace carries the heavy values and the value range of one
+ * build to the next build of n keys (as mc_rank_build's does; results never depend on it); mc_rank_runs_forget
+ * clears that. */
+size_t mc_rank_runs_workspace_bytes(uint64_t n);
+uint64_t mc_rank_runs_capacity(uint64_t n);
+uint64_t mc_rank_runs_max_keys(void);
+int mc_rank_runs_build(const double *keys_in, uint64_t n, uint64_t n_global, double *vals, uint64_t *cum_count,
+                       double *cum_pos, uint64_t capacity, uint64_t *info, void *workspace, size_t workspace_bytes,
+                       void *stream);
+int mc_rank_runs_forget(void *workspace, uint64_t n, void *stream);
+/* Synchronises `stream` and copies info to the host (host_info may be NULL): MC_OK, MC_ERR_UNSUITED (see above) or
+ * MC_ERR_WORKSPACE (the keys changed while the build ran).  No counterpart in the reference. */
+int mc_rank_runs_check(const uint64_t *info, void *stream, uint64_t host_info[8]);
+/* ml2p2rank (lib4mc/MonteCarloLib.py:30-32) on the run index: out_cnt = bisect_right(sorted keys, x) =
+ * cum_count of the last run at or below x (0: none), out_pos = its cum_pos (0.0: none) -- what mc_rank_query
+ * returns on the arrays of mc_rank_build.  A failed index answers NaN / 0. */
+int mc_rank_runs_query(const double *vals, const uint64_t *cum_count, const double *cum_pos, const uint64_t *info,
+                       const double *x, uint64_t t, double *out_pos, uint64_t *out_cnt, void *stream);
+/* The arrays the reference keeps (lib4mc/MonteCarloLib.py:11, :24-27), written from the runs for callers that
+ * look at them (MonteCarloLib sorts the caller's list in place): keys_sorted[n] and / or positions[n] (either
+ * may be NULL); positions inside a run of c copies of v grow by 2^(v - log2 n_global) a copy.  A failed index
+ * fills both with NaN. */
+int mc_rank_runs_expand(const double *vals, const uint64_t *cum_count, const double *cum_pos, const uint64_t *info,
+                        uint64_t n, uint64_t n_global, double *keys_sorted, double *positions, void *stream);
 
 /* ml2p2rank (lib4mc/MonteCarloLib.py:30-32) for t queries: cnt = bisect_right(keys_sorted, x),
  * pos = positions[cnt-1] or 0.0 when cnt == 0 (the caller maps a global cnt of 0 to the

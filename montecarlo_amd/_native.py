@@ -32,6 +32,7 @@ LINES_COUNT, LINES_OFF, LINES_CPS, LINES_INFO = range(4)
 ENUM_ML2P, ENUM_LEN, ENUM_SYMS = range(3)
 COUNTS_ENT_COUNT = 16
 ERR_DIVERGED = -5
+ERR_UNSUITED = -7
 
 u32p = C.POINTER(C.c_uint32)
 u64p = C.POINTER(C.c_uint64)
@@ -131,6 +132,14 @@ def _load() -> C.CDLL:
         "mc_allreduce_rank": (C.c_int, [vp, vp, vp, C.c_uint64, vp]),
         "mc_comm_destroy": (None, [vp]),
         "mc_rank_query": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp]),
+        "mc_rank_runs_workspace_bytes": (C.c_size_t, [C.c_uint64]),
+        "mc_rank_runs_capacity": (C.c_uint64, [C.c_uint64]),
+        "mc_rank_runs_max_keys": (C.c_uint64, []),
+        "mc_rank_runs_build": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, vp, vp, C.c_uint64, vp, vp, C.c_size_t, vp]),
+        "mc_rank_runs_forget": (C.c_int, [vp, C.c_uint64, vp]),
+        "mc_rank_runs_check": (C.c_int, [vp, vp, u64p]),
+        "mc_rank_runs_query": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp]),
+        "mc_rank_runs_expand": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.c_uint64, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = header and library disagree
@@ -143,7 +152,8 @@ EXPORTS = ["mc_abi_version", "mc_last_error", "mc_table_compile", "mc_table_free
            "mc_ctx_hash", "mc_text_hash", "mc_score_words_workspace_bytes", "mc_score_words", "mc_score_bpe", "mc_train_nwords", "mc_train_backwords", "mc_train_v2", "mc_trained_free", "mc_counts_new", "mc_counts_free",
            "mc_counts_merge", "mc_counts_train", "mc_counts_import", "mc_counts_array", "mc_trained_array", "mc_trained_compile", "mc_lines_ingest", "mc_lines_free", "mc_lines_array", "mc_format_gc", "mc_format_gc_cps", "mc_model_upload", "mc_model_destroy", "mc_model_check", "mc_sample", "mc_sample_carry", "mc_sample_tune", "mc_sample_injected", "mc_sample_dedup",
            "mc_score", "mc_rank_workspace_bytes", "mc_rank_build", "mc_rank_check", "mc_rank_debug_fail", "mc_rank_debug_search", "mc_workspace_forget", "mc_rank_noalloc_max_keys", "mc_rank_build_noalloc", "mc_rank_query", "mc_order_workspace_bytes", "mc_order_keys", "mc_guess_numbers_workspace_bytes", "mc_guess_numbers", "mc_comm_unique_id", "mc_comm_init", "mc_allreduce_rank", "mc_comm_destroy", "mc_enumerate", "mc_enum_info", "mc_enum_fetch",
-           "mc_enum_free"]
+           "mc_enum_free", "mc_rank_runs_workspace_bytes", "mc_rank_runs_capacity", "mc_rank_runs_max_keys", "mc_rank_runs_build",
+           "mc_rank_runs_forget", "mc_rank_runs_check", "mc_rank_runs_query", "mc_rank_runs_expand"]
 
 
 def check(rc: int) -> int:

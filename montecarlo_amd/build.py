@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmi355mc.so")
-SOURCES = ["mc_table.cpp", "mc_train.cpp", "mc_ingest.cpp", "mc_device.hip", "mc_rank.hip", "mc_sort.hip", "mc_gn.hip", "mc_enum.hip", "mc_comm.cpp"]
+SOURCES = ["mc_table.cpp", "mc_train.cpp", "mc_ingest.cpp", "mc_device.hip", "mc_rank.hip", "mc_sort.hip", "mc_runs.hip", "mc_gn.hip", "mc_enum.hip", "mc_comm.cpp"]
 HEADERS = [os.path.join(CSRC, "mc_internal.h"), os.path.join(CSRC, "mc_sort.h"), os.path.join(os.path.dirname(HERE), "include", "mi355mc.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-ldl"]

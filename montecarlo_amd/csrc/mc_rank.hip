@@ -205,10 +205,22 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_positions(const double *__rest
 // of the two is found in rounds of 32 probes (5 rounds for 1e7 keys instead of 24 dependent reads a lane); test
 // passwords usually arrive in ascending order of x (mc_order_keys), so what is left to a lane is a few steps.
 // Any order of x is answered correctly (the bracket is wide then), NaN as by the plain search (cnt = n).
-__global__ void __launch_bounds__(256) k_query(const double *__restrict__ keys, const double *__restrict__ pos, u64 n,
+// RUNS: the arrays are the run index of csrc/mc_runs.hip (distinct values, their cumulative positions and counts);
+// their length and the build's error word come from `info` on the device.
+template <bool RUNS>
+__global__ void __launch_bounds__(256) k_query(const double *__restrict__ keys, const double *__restrict__ pos, u64 n_arg,
                                                const double *__restrict__ x, u64 t, double *__restrict__ out_pos,
-                                               u64 *__restrict__ out_cnt) {
+                                               u64 *__restrict__ out_cnt, const u64 *__restrict__ ccum,
+                                               const u64 *__restrict__ info) {
     const int lane = threadIdx.x & 63;
+    const u64 n = RUNS ? info[0] : n_arg;
+    if (RUNS && info[1]) {  // a failed build must not pass for a result
+        for (u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x; q < t; q += (u64)gridDim.x * blockDim.x) {
+            out_pos[q] = __longlong_as_double(0x7FF8000000000000ll);
+            if (out_cnt) out_cnt[q] = 0;
+        }
+        return;
+    }
     for (u64 q0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) - lane; q0 < t; q0 += (u64)gridDim.x * blockDim.x) {
         const u64 q = q0 + lane;
         const bool act = q < t;
@@ -250,7 +262,7 @@ __global__ void __launch_bounds__(256) k_query(const double *__restrict__ keys, 
                 const u64 mid = (lo + hi) >> 1;
                 if (keys[mid] > v) hi = mid; else lo = mid + 1;
             }
-            if (out_cnt) out_cnt[q] = lo;
+            if (out_cnt) out_cnt[q] = RUNS ? (lo ? ccum[lo - 1] : 0ull) : lo;
             out_pos[q] = lo ? pos[lo - 1] : 0.0;
         }
     }
@@ -426,8 +438,24 @@ extern "C" int mc_rank_query(const double *keys_sorted, const double *positions,
     }
     u64 want = (t + 255) / 256;
     u32 g = (u32)(want < 4096 ? want : 4096);
-    hipLaunchKernelGGL(k_query, dim3(g), dim3(256), 0, (hipStream_t)stream, keys_sorted, positions, (u64)n, x, (u64)t,
-                       out_pos, (u64 *)out_cnt);
+    hipLaunchKernelGGL(k_query<false>, dim3(g), dim3(256), 0, (hipStream_t)stream, keys_sorted, positions, (u64)n, x,
+                       (u64)t, out_pos, (u64 *)out_cnt, (const u64 *)nullptr, (const u64 *)nullptr);
+    HIP_TRY(hipGetLastError());
+    return MC_OK;
+}
+
+extern "C" int mc_rank_runs_query(const double *vals, const uint64_t *cum_count, const double *cum_pos,
+                                  const uint64_t *info, const double *x, uint64_t t, double *out_pos,
+                                  uint64_t *out_cnt, void *stream) {
+    if (t == 0) return MC_OK;
+    if (!x || !out_pos || !vals || !cum_count || !cum_pos || !info) {
+        mc_set_error("mc_rank_runs_query: bad argument");
+        return MC_ERR_ARG;
+    }
+    u64 want = (t + 255) / 256;
+    u32 g = (u32)(want < 4096 ? want : 4096);
+    hipLaunchKernelGGL(k_query<true>, dim3(g), dim3(256), 0, (hipStream_t)stream, vals, cum_pos, (u64)0, x, (u64)t,
+                       out_pos, (u64 *)out_cnt, (const u64 *)cum_count, (const u64 *)info);
     HIP_TRY(hipGetLastError());
     return MC_OK;
 }

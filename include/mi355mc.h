@@ -492,6 +492,11 @@ int mc_rank_runs_query(const double *vals, const uint64_t *cum_count, const doub
 int mc_rank_runs_expand(const double *vals, const uint64_t *cum_count, const double *cum_pos, const uint64_t *info,
                         uint64_t n, uint64_t n_global, double *keys_sorted, double *positions, void *stream);
 
+/* Development aid, no counterpart in the reference: on != 0 makes the run-index builds that follow add the clock
+ * ticks (100 MHz) their workgroups spend per phase to 16 device counters; out (may be NULL) receives the counters
+ * gathered so far and clears them.  Synchronises the device. */
+int mc_rank_runs_debug_phases(int on, uint64_t out[16]);
+
 /* ml2p2rank (lib4mc/MonteCarloLib.py:30-32) for t queries: cnt = bisect_right(keys_sorted, x),
  * pos = positions[cnt-1] or 0.0 when cnt == 0 (the caller maps a global cnt of 0 to the
  * reference's `1`, after summing shards). */

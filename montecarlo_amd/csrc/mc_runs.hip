@@ -67,8 +67,8 @@ constexpr int SNIFF_S = 16384, SNIFF_SLOTS = 16384, SNIFF_MIN = 5, SNIFF_THREADS
 constexpr int SNIFF_BLOCK = 16;    // consecutive keys per sampled block
 constexpr int TBUF = TILE;         // tail keys per batch (a tile adds at most TILE keys: one flush per tile at most)
 constexpr int P_MAX = 1024;        // bins at most
-constexpr int BSLOTS = 4096;       // slots of a bin's counting table
-constexpr int CAPD = 2048;         // distinct values a bin may hold
+constexpr int CELLS = 4096;        // equal cells of the value range; a bin is a run of cells (the map's look-up table)
+constexpr int CAPD = 2048;         // distinct values a bin may hold (k_rl_bins: MAIN_CAP + OVCAP)
 constexpr u64 EMPTY = ~0ull;
 constexpr u64 RUNS_MAX_N = 1ull << 26;
 constexpr u64 F64_INF = 0x7FF0000000000000ull;
@@ -93,6 +93,10 @@ struct RWs {
     const u64 *in;
     u64 *tail;       // [n] region r's batches at r * region + j * TBUF, each ordered by bin
     u32 *nbatch;     // [regions] batches region r wrote
+    u64 *rmax;       // [regions] largest finite tail key of region r (bit pattern; 0: none)
+    u32 *hbin;       // [P + 1] first heavy value (index into `heavy`) that lies in bin b or above
+    unsigned short *lut;    // [CELLS] bin of every cell of the value range (monotone)
+    unsigned short *cell0;  // [P + 1] first cell of bin b (cell0[P] = CELLS; an empty bin: cell0[b] = cell0[b + 1])
     u32 *start;      // [regions * nb][P + 1] offsets of the bins inside a batch
     u64 *rval;       // [P * CAPD] a bin's distinct values, ascending
     u64 *rccum;      // [P * CAPD] ... copies up to and including each, inside the bin
@@ -106,6 +110,7 @@ struct RWs {
     // outputs (the caller's)
     u64 *out_vals, *out_ccum;
     double *out_wcum;
+    u64 *phase;      // development aid (mc_rank_runs_debug_phases): per-phase clock sums of k_rl_bins / k_rl_strip, or null
     u64 *out_info;   // {distinct values, error word, keys counted, heavy values, tail keys, builds the list has served, 0, 0}
     u64 out_cap;
 };
@@ -186,30 +191,34 @@ __device__ __forceinline__ u32 mix32(u64 k) {
 }
 __device__ __forceinline__ u32 strip_hash(u64 k) { return mix32(k) >> 21; }  // 11 bits = HSET slots
 
-// The bin of a key: monotone in the key's BIT pattern (the order the index is kept in; for the non-negative doubles
-// it is made for, the numeric order): below lo -> 0, at or above hi (infinities, NaNs, a set sign bit) -> P - 1.
+// The bin of a key: the range [lo, hi] the sample saw (widened) is cut into CELLS equal cells, and a look-up table
+// made from the sample's own distribution gives every cell its bin, so that the bins hold about equally many keys
+// (equal-width bins held up to seven times the mean where the scores are densest, and the workgroups of those bins
+// set k_rl_bins' time).  Monotone in the key's BIT pattern (the order the index is kept in; for the non-negative
+// doubles it is made for, the numeric order): below lo -> cell 0, at or above hi (infinities, NaNs, a set sign bit)
+// -> the last cell.
 struct BinMap {
     u64 lo_bits, hi_bits;
-    double lo, scale;
-    u32 P;
+    double lo, cscale;
+    const unsigned short *lut;  // (LDS or memory)
 };
-__device__ __forceinline__ BinMap bin_map(const RCtl *c, u32 P) {
+__device__ __forceinline__ BinMap bin_map(double lo, double hi, const unsigned short *lut) {
     BinMap m;
-    m.lo = c->map_lo;
-    const double hi = c->map_hi;
+    m.lo = lo;
     m.lo_bits = (u64)__double_as_longlong(m.lo);
     m.hi_bits = (u64)__double_as_longlong(hi);
-    m.scale = hi > m.lo ? (double)P / (hi - m.lo) : 0.0;
-    m.P = P;
+    m.cscale = hi > m.lo ? (double)CELLS / (hi - m.lo) : 0.0;
+    m.lut = lut;
     return m;
 }
-__device__ __forceinline__ u32 bin_of(const BinMap &m, u64 kb) {
-    if (kb >= m.hi_bits) return m.P - 1;
+__device__ __forceinline__ u32 cell_of(const BinMap &m, u64 kb) {
+    if (kb >= m.hi_bits) return CELLS - 1;
     if (kb <= m.lo_bits) return 0u;
-    const double x = (__longlong_as_double((long long)kb) - m.lo) * m.scale;
-    const u32 b = (u32)x;
-    return b < m.P ? b : m.P - 1;
+    const double x = (__longlong_as_double((long long)kb) - m.lo) * m.cscale;
+    const u32 c = (u32)x;
+    return c < (u32)CELLS ? c : (u32)CELLS - 1;
 }
+__device__ __forceinline__ u32 bin_of(const BinMap &m, u64 kb) { return m.lut[cell_of(m, kb)]; }
 
 // ---- the sample: heavy values and the range of the rest ------------------------------------------------------
 __device__ __forceinline__ bool sample_index(u32 n, u32 q, u64 &idx) {
@@ -383,8 +392,12 @@ __global__ void __launch_bounds__(SNIFF_THREADS) k_rl_sniff(RWs w) {
             if (r) atomicAdd(&rank[i], r);
         }
         __syncthreads();
-        for (u32 i2 = tid; i2 < H; i2 += SNIFF_THREADS) w.heavy[rank[i2]] = list[i2];
+        for (u32 i2 = tid; i2 < H; i2 += SNIFF_THREADS) {
+            w.heavy[rank[i2]] = list[i2];
+            ((u64 *)tag)[rank[i2]] = list[i2];  // (the tags are not needed any more: the list in ascending order)
+        }
     }
+    __shared__ double s_lo, s_hi;
     if (tid == 0) {
         u64 mn = EMPTY, mx = 0;
         for (int i = 0; i < SNIFF_THREADS / 64; ++i) {
@@ -396,7 +409,7 @@ __global__ void __launch_bounds__(SNIFF_THREADS) k_rl_sniff(RWs w) {
             lo = __longlong_as_double((long long)mn);
             hi = __longlong_as_double((long long)mx);
             // a sample sees the middle of the distribution: the range is widened so that the ends, which only the
-            // full input reaches, spread over bins of their own instead of piling up in the first and the last
+            // full input reaches, spread over cells of their own instead of piling up in the first and the last
             const double range = hi - lo;
             lo = lo - 0.10 * range;
             if (lo < 0.0) lo = 0.0;
@@ -415,11 +428,82 @@ __global__ void __launch_bounds__(SNIFF_THREADS) k_rl_sniff(RWs w) {
         c->list_age = 0;
         c->map_lo = lo;
         c->map_hi = hi;
+        s_lo = lo;
+        s_hi = hi;
+    }
+    // ---- the look-up table: cells of the range -> bins of about equal numbers of (non-heavy) sample keys ----
+    static_assert(CELLS == 4 * SNIFF_THREADS, "a thread scans four cells");
+    static_assert(SNIFF_SLOTS / 2 >= CELLS && SNIFF_SLOTS >= 2 * H_MAX + CELLS / 2, "the histogram borrows tc, the table borrows tag");
+    u32 *hist = tc;                                        // (the ranks that lived here are dead after the barrier below)
+    unsigned short *slut = (unsigned short *)(tag + 2 * H_MAX);  // (behind the sorted list)
+    __shared__ u32 wtot16[SNIFF_THREADS / 64];
+    __syncthreads();
+    for (u32 i = tid; i < (u32)CELLS; i += SNIFF_THREADS) hist[i] = 0;
+    __syncthreads();
+    {
+        const BinMap cm = bin_map(s_lo, s_hi, nullptr);
+#pragma unroll
+        for (int q = 0; q < PER; ++q)
+            if (have[q] && k[q] < F64_INF && !over[q]) atomicAdd(&hist[cell_of(cm, k[q])], 1u);
+    }
+    __syncthreads();
+    {
+        const u32 c4[4] = {hist[4 * tid], hist[4 * tid + 1], hist[4 * tid + 2], hist[4 * tid + 3]};
+        const u32 mine = c4[0] + c4[1] + c4[2] + c4[3];
+        u32 inc = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) wtot16[wid] = inc;
+        __syncthreads();
+        u32 off = 0, total = 0;
+        for (int i = 0; i < SNIFF_THREADS / 64; ++i) {
+            if (i < wid) off += wtot16[i];
+            total += wtot16[i];
+        }
+        u32 before = off + inc - mine;  // sample keys in the cells before this thread's four
+        // a cell's bin: a quarter from the share of the sample below it, three quarters from the cell's own place in
+        // the range.  Equal-width bins hold up to 43,000 of the headline step's 1.96e6 tail keys (the mean is 1900)
+        // and at most 921 distinct values; bins of equal numbers of keys grow wide where keys are few but all
+        // different (3127 distinct values in one); at a quarter the fullest bin holds 19,000 keys and 1231 values
+        // (scripts/bin_stats.py)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32 c = 4 * tid + j;
+            const double lin = (double)c / (double)CELLS;
+            const double f = total ? 0.25 * ((double)before / (double)total) + 0.75 * lin : lin;
+            u32 bin = (u32)(f * (double)w.P);
+            if (bin >= w.P) bin = w.P - 1;
+            slut[c] = (unsigned short)bin;
+            w.lut[c] = (unsigned short)bin;
+            before += c4[j];
+        }
+    }
+    __syncthreads();
+    {   // where every bin starts among the cells and among the heavy values (the map is monotone: both are runs)
+        const BinMap bm = bin_map(s_lo, s_hi, slut);
+        const u64 *sorted = (const u64 *)tag;
+        for (u32 b = tid; b <= w.P; b += SNIFF_THREADS) {
+            u32 lo = 0, hi = CELLS;  // first cell whose bin is >= b
+            while (lo < hi) {
+                const u32 mid = (lo + hi) >> 1;
+                if (slut[mid] >= b) hi = mid; else lo = mid + 1;
+            }
+            w.cell0[b] = (unsigned short)(b == w.P ? (u32)CELLS : lo);
+            lo = 0, hi = H;  // first i with bin_of(sorted[i]) >= b
+            while (lo < hi) {
+                const u32 mid = (lo + hi) >> 1;
+                if (bin_of(bm, sorted[mid]) >= b) hi = mid; else lo = mid + 1;
+            }
+            w.hbin[b] = b == w.P ? H : lo;
+        }
     }
 }
 
 // ---- strip: count the copies of heavy values, order the rest by bin ------------------------------------------
-__global__ void __launch_bounds__(WG) k_rl_strip(RWs w) {
+__global__ void __launch_bounds__(WG, 4) k_rl_strip(RWs w) {  // (4 waves per SIMD = two workgroups a CU)
     static_assert(HSET == 2048, "strip_hash yields 11 bits");
     static_assert(TBUF == TILE && TBUF == ITEMS * WG, "a batch is flushed by the whole workgroup, ITEMS keys a lane");
     static_assert(P_MAX == 2 * WG, "the scan of the bins' counts takes two bins a thread");
@@ -428,16 +512,19 @@ __global__ void __launch_bounds__(WG) k_rl_strip(RWs w) {
     __shared__ u32 hi[HSET];       // slot -> index of the heavy value
     __shared__ u64 tb[TBUF];       // tail keys waiting for their batch
     __shared__ u32 bh[P_MAX + 1];  // keys per bin of the batch, then the bins' offsets
+    __shared__ unsigned short slut[CELLS];  // the map's look-up table
     __shared__ u32 wtot[NWAVE];
+    __shared__ u64 wmx[NWAVE];
     __shared__ u32 tfill;
     const int tid = threadIdx.x, lane = tid & 63;
     const u32 H = w.ctl->n_heavy <= (u32)H_MAX ? w.ctl->n_heavy : 0u;
     const u32 n = w.n, P = w.P;
-    const BinMap bm = bin_map(w.ctl, P);
+    const BinMap bm = bin_map(w.ctl->map_lo, w.ctl->map_hi, slut);
     for (u32 i = tid; i <= (u32)HSET; i += WG) {
         hk[i] = EMPTY;
         hs[i] = 0;
     }
+    for (u32 i = tid; i < (u32)CELLS / 2; i += WG) ((u32 *)slut)[i] = ((const u32 *)w.lut)[i];
     __syncthreads();
     for (u32 i = tid; i < H; i += WG) {
         const u64 v = w.heavy[i];
@@ -483,13 +570,26 @@ __global__ void __launch_bounds__(WG) k_rl_strip(RWs w) {
         if (tid == 0) bh[P_MAX] = m;
         __syncthreads();
         for (u32 i = tid; i <= P; i += WG) row[i] = bh[i];  // (bins >= P are empty: bh[P] = m)
+        // the keys change places inside the buffer (every lane holds its own in registers) and leave it in order,
+        // consecutive lanes on consecutive addresses (written from where they lay, every key was a request of its
+        // own to the L2: 1.7e6 of them for the 1.96e6 tail keys of the headline step)
 #pragma unroll
         for (int q = 0; q < ITEMS; ++q) {
             const u32 i = q * WG + tid;
             if (i < m) {
                 const u32 at = bh[bin[q]] + rk[q];
-                if (at < room) out[at] = key[q]; else atomicOr(&w.ctl->err, ERR_RANGE);
+                if (at < m) tb[at] = key[q]; else atomicOr(&w.ctl->err, ERR_RANGE);
             }
+        }
+        __syncthreads();
+        if (m > room) {
+            if (tid == 0) atomicOr(&w.ctl->err, ERR_RANGE);
+            m = room;
+        }
+#pragma unroll
+        for (int q = 0; q < ITEMS; ++q) {
+            const u32 i = q * WG + tid;
+            if (i < m) out[i] = tb[i];
         }
         __syncthreads();
     };
@@ -498,6 +598,7 @@ __global__ void __launch_bounds__(WG) k_rl_strip(RWs w) {
         const u64 lo = (u64)r * w.region;
         const u32 rn = (u32)(n - lo < (u64)w.region ? n - lo : (u64)w.region);
         u32 nbat = 0;
+        u64 kmx = 0;  // largest finite tail key this thread saw
         if (tid == 0) tfill = 0;
         __syncthreads();
         u64 k[ITEMS], nk[ITEMS];
@@ -571,6 +672,7 @@ __global__ void __launch_bounds__(WG) k_rl_strip(RWs w) {
                 const bool tail = (tmask[q] >> lane) & 1ull;
                 pos[q] = tail ? base + (u32)__popcll(tmask[q] & lt) : 0xFFFFFFFFu;
                 if (tail && pos[q] < (u32)TBUF) tb[pos[q]] = k[q];
+                if (tail && k[q] < F64_INF && k[q] > kmx) kmx = k[q];
                 base += (u32)__popcll(tmask[q]);
             }
             __syncthreads();
@@ -600,7 +702,15 @@ __global__ void __launch_bounds__(WG) k_rl_strip(RWs w) {
             ++nbat;
             if (tid == 0) tail_total += m;
         }
-        if (tid == 0) w.nbatch[r] = nbat < w.nb ? nbat : w.nb;
+        kmx = wave_max(kmx);
+        if (lane == 0) wmx[tid >> 6] = kmx;
+        __syncthreads();
+        if (tid == 0) {
+            u64 m2 = 0;
+            for (int i = 0; i < NWAVE; ++i) m2 = wmx[i] > m2 ? wmx[i] : m2;
+            w.rmax[r] = m2;
+            w.nbatch[r] = nbat < w.nb ? nbat : w.nb;
+        }
         __syncthreads();
     }
     if (tid == 0 && tail_total) atomicAdd(&w.ctl->n_tail, tail_total);
@@ -621,130 +731,365 @@ __global__ void __launch_bounds__(WG) k_rl_strip(RWs w) {
         if (hc[i]) atomicAdd(&w.hcnt[i], hc[i]);
 }
 
-// ---- one bin: count, sort, scan ------------------------------------------------------------------------------
-__global__ void __launch_bounds__(WG) k_rl_bins(RWs w) {
-    __shared__ u64 tk[BSLOTS];   // the counting table, then the sorted values
-    __shared__ u32 tc[BSLOTS];   // ... their counts
-    __shared__ u64 ev[CAPD];     // the table's entries, compacted
-    __shared__ u32 ec[CAPD];
-    __shared__ u64 wt64[NWAVE];
-    __shared__ double wtf[NWAVE];
-    __shared__ u32 dcount, ecnt, over;
-    const int tid = threadIdx.x;
+// development aid: where a workgroup's time goes (sums over the workgroups, in ticks of the 100 MHz wall clock)
+#define PHASE_MARK(slot)                                                     \
+    do {                                                                     \
+        if (w.phase && threadIdx.x == 0) {                                   \
+            const u64 now_ = wall_clock64();                                 \
+            atomicAdd(&w.phase[slot], now_ - t_phase);                       \
+            t_phase = now_;                                                  \
+        }                                                                    \
+    } while (0)
+
+// ---- one bin: count, order, scan ------------------------------------------------------------------------------
+// The bin's table is addressed by VALUE: the bin's range is cut into SUB equal sub-ranges and a value's slot is its
+// sub-range -- monotone, so that the occupied slots in slot order ARE the distinct values in ascending order: no
+// sort.  A bin holds a few hundred distinct values as a rule; two of them in one sub-range (d^2 / 2 SUB pairs: a
+// handful) send the later comer to a small hash table (the "overflow"), whose values are ranked by counting and
+// merged into the order.  More than OVCAP overflow values or MAIN_CAP occupied sub-ranges -- a thousand distinct
+// values in the bin, or values that differ only far below the bin's width -- and the keys do not suit the index
+// (ERR_BIN).  Bin 0 reaches down to 0.0 and bin P - 1 up to the largest finite key; infinities, NaNs and negative
+// numbers (bit patterns above +inf) have no sub-range and go to the overflow table, which orders by bits.
+//
+// What decides the time is the length of the chains of dependent memory and LDS operations, not their number (a
+// bin is 1900 keys): a lane asks for all the keys of its segment at once and for all their slots at once (one
+// compare-and-swap each, the count is added without waiting).  Tried before: a hash table compacted and ranked all
+// against all, 512 lanes a bin, the keys found by a search over the segments' prefix sums (74-97 us for the 1024
+// bins of 1e7 keys: twenty barriers around chains of LDS round trips); the same with one wave a bin (551 us: every
+// round trip exposed).
+constexpr int BW = 256;            // lanes of k_rl_bins' workgroup
+constexpr int BNW = BW / 64;
+constexpr int SUB = 2048;          // sub-ranges of a bin
+constexpr int BSL = SUB / BW;      // sub-ranges a lane scans
+constexpr int MAIN_CAP = 1536;     // occupied sub-ranges a bin may have
+constexpr int OVS = 1024, OVCAP = 512;  // overflow: hash table of OVS slots, at most OVCAP values
+constexpr int SEG_MAX = STRIP_SLOTS;   // regions (one segment of a bin each per round of batches)
+constexpr int RK = SEG_MAX / BW;   // regions a lane looks after
+constexpr int KU = 16;             // key loads of a lane in flight
+
+// inclusive prefix over the workgroup in thread order (every thread calls; wt: BNW entries)
+template <typename T>
+__device__ __forceinline__ T bins_incl_scan(T v, T *wt, T &total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    T inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const T t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads();
+    if (lane == 63) wt[wid] = inc;
+    __syncthreads();
+    T off = (T)0, tot = (T)0;
+#pragma unroll
+    for (int i = 0; i < BNW; ++i) {
+        const T t = wt[i];
+        if (i < wid) off += t;
+        tot += t;
+    }
+    total = tot;
+    return off + inc;
+}
+
+__global__ void __launch_bounds__(BW) k_rl_bins(RWs w) {
+    static_assert(SUB % BW == 0 && OVS % BW == 0 && SEG_MAX % BW == 0, "whole rounds of the workgroup");
+    static_assert(MAIN_CAP + OVCAP <= CAPD, "a bin's runs fit its place in the workspace");
+    static_assert(SUB + OVCAP < 65536, "entry ids are 16 bits");
+    __shared__ u64 tk[SUB];      // value by sub-range
+    __shared__ u32 tc[SUB];      // ... its copies
+    __shared__ u64 ovk[OVS];     // overflow: hash table while counting, ascending list afterwards
+    __shared__ u32 ovc[OVS];
+    __shared__ u64 osk[OVCAP];   // (the overflow table, compacted)
+    __shared__ u32 osc[OVCAP];
+    __shared__ unsigned short ids[MAIN_CAP];          // occupied sub-ranges, ascending
+    __shared__ unsigned short ord[MAIN_CAP + OVCAP];  // entry ids in ascending order of value
+    __shared__ u32 wt32[BNW];
+    __shared__ u64 wt64[BNW];
+    __shared__ double wtf[BNW];
+    __shared__ u64 wmx[BNW];
+    __shared__ u32 nov, over;
+    const int tid = threadIdx.x, lane = tid & 63;
     const u32 b = blockIdx.x, P = w.P;
-    const BinMap bm = bin_map(w.ctl, P);
-    for (u32 i = tid; i < (u32)BSLOTS; i += WG) {
+    // everything the bin needs from memory is asked for at once: the map, where its heavy values start, and per
+    // region its count of batches and its first batch's offsets of bin b (a region holds one batch as a rule)
+    const double map_lo = w.ctl->map_lo, map_hi = w.ctl->map_hi;
+    const u32 hb0 = w.hbin[b], hb1 = w.hbin[b + 1];
+    const u32 cl0 = w.cell0[b], cl1 = w.cell0[b + 1];
+    const bool last = cl1 == (u32)CELLS && cl0 < cl1;  // the bin of the last cell: everything from hi upwards is its
+    u32 nbt[RK], f0[RK], f1[RK];
+    u64 rmx = 0;
+#pragma unroll
+    for (int k = 0; k < RK; ++k) {
+        const u32 r = k * BW + tid;
+        nbt[k] = f0[k] = f1[k] = 0;
+        if (r < w.regions) {
+            const u32 *row0 = w.start + (size_t)r * w.nb * (P + 1);
+            nbt[k] = w.nbatch[r];
+            f0[k] = row0[b];
+            f1[k] = row0[b + 1];
+            if (last) {
+                const u64 m = w.rmax[r];
+                rmx = m > rmx ? m : rmx;
+            }
+        }
+    }
+    u64 t_phase = w.phase ? wall_clock64() : 0ull;
+    const u64 t_first = t_phase;
+    for (u32 i = tid; i < (u32)SUB; i += BW) {
         tk[i] = EMPTY;
         tc[i] = 0;
     }
-    if (tid == 0) dcount = ecnt = over = 0;
+    for (u32 i = tid; i < (u32)OVS; i += BW) {
+        ovk[i] = EMPTY;
+        ovc[i] = 0;
+    }
+    if (tid == 0) nov = over = 0;
+    // the bin's own range [base, top) and its sub-ranges
+    const double cw = (map_hi - map_lo) / (double)CELLS;
+    const double base = cl0 ? map_lo + (double)cl0 * cw : 0.0;  // (the bin of cell 0 reaches down to 0.0)
+    double top = map_lo + (double)cl1 * cw;
+    if (last) {  // (uniform) up to the largest finite key there is
+        rmx = wave_max(rmx);
+        if (lane == 0) wmx[tid >> 6] = rmx;
+        __syncthreads();
+        u64 m2 = 0;
+        for (int i = 0; i < BNW; ++i) m2 = wmx[i] > m2 ? wmx[i] : m2;
+        const u32 Hn = w.ctl->n_heavy <= (u32)H_MAX ? w.ctl->n_heavy : 0u;
+        for (u32 i = Hn; i > 0 && i + 4 > Hn; --i) {  // (the list's last values: the largest finite one of them)
+            const u64 v = w.heavy[i - 1];
+            if (v < F64_INF) {
+                m2 = v > m2 ? v : m2;
+                break;
+            }
+        }
+        const double km = __longlong_as_double((long long)m2);
+        if (km >= top) top = km * (1.0 + 0x1.0p-40) + 0x1.0p-1000;  // (strictly above: km itself lands in the last sub-range)
+    }
+    if (!(top > base)) top = base + 1.0;
+    const double sscale = (double)SUB / (top - base);
+    auto slot_of = [&](u64 kb) -> u32 {
+        if (kb >= F64_INF) return (u32)SUB;  // no sub-range
+        const double x = (__longlong_as_double((long long)kb) - base) * sscale;
+        if (!(x > 0.0)) return 0u;
+        return x < (double)SUB ? (u32)x : (u32)SUB - 1u;
+    };
     __syncthreads();
-    auto insert = [&](u64 key, u32 c) {
-        u32 s = (mix32(key) >> 8) & (BSLOTS - 1);
-        for (u32 probe = 0; probe < (u32)BSLOTS; ++probe) {
+    PHASE_MARK(0);
+    auto ov_insert = [&](u64 key, u32 c) {  // (rare)
+        u32 h = (mix32(key) >> 9) & (OVS - 1);
+        for (u32 probe = 0; probe < (u32)OVS; ++probe) {
             if (__hip_atomic_load(&over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
-            const u64 cur = __hip_atomic_load(&tk[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const u64 cur = __hip_atomic_load(&ovk[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (cur == key) {
-                atomicAdd(&tc[s], c);
+                atomicAdd(&ovc[h], c);
                 return;
             }
             if (cur == EMPTY) {
-                const u64 old = atomicCAS(&tk[s], EMPTY, key);
+                const u64 old = atomicCAS(&ovk[h], EMPTY, key);
                 if (old == EMPTY) {
-                    if (atomicAdd(&dcount, 1u) >= (u32)CAPD) atomicOr(&over, 1u);
-                    atomicAdd(&tc[s], c);
+                    if (atomicAdd(&nov, 1u) >= (u32)OVCAP) atomicOr(&over, 1u);
+                    atomicAdd(&ovc[h], c);
                     return;
                 }
                 if (old == key) {
-                    atomicAdd(&tc[s], c);
+                    atomicAdd(&ovc[h], c);
                     return;
                 }
             }
-            s = (s + 1) & (BSLOTS - 1);
+            h = (h + 1) & (OVS - 1);
         }
         atomicOr(&over, 1u);
     };
-    // the heavy values that fall into this bin, with the copies k_rl_strip counted
-    const u32 H = w.ctl->n_heavy <= (u32)H_MAX ? w.ctl->n_heavy : 0u;
-    for (u32 i = tid; i < H; i += WG) {
-        const u64 v = w.heavy[i];
-        const u32 c = w.hcnt[i];
-        if (c && v != EMPTY && bin_of(bm, v) == b) insert(v, c);
-    }
-    // the bin's segment of every batch
-    for (u32 r = tid; r < w.regions; r += WG) {
-        const u32 nbt = w.nbatch[r] <= w.nb ? w.nbatch[r] : 0u;
-        for (u32 j = 0; j < nbt; ++j) {
-            const u32 *row = w.start + ((size_t)r * w.nb + j) * (P + 1);
-            const u32 s0 = row[b], s1 = row[b + 1];
-            const u64 base = (u64)r * w.region + (u64)j * TBUF;
-            if (s1 > (u32)TBUF || s0 > s1 || base + s1 > (u64)w.n) {  // (offsets are checked before they are believed)
-                atomicOr(&w.ctl->err, ERR_RANGE);
-                continue;
-            }
-            for (u32 i = s0; i < s1; ++i) insert(w.tail[base + i], 1u);
+    // counts n keys of a lane: all their slots are asked for before the first answer is looked at
+    auto count = [&](const u64 (&key)[KU], const u32 (&c)[KU], u32 n) {
+        u32 s[KU];
+        u64 old[KU];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) s[u] = (u32)u < n ? slot_of(key[u]) : (u32)SUB;
+#pragma unroll
+        for (int u = 0; u < KU; ++u) old[u] = s[u] < (u32)SUB ? atomicCAS(&tk[s[u]], EMPTY, key[u]) : 0ull;
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            if ((u32)u >= n) continue;
+            if (s[u] < (u32)SUB && (old[u] == EMPTY || old[u] == key[u])) atomicAdd(&tc[s[u]], c[u]);
+            else ov_insert(key[u], c[u]);
+        }
+    };
+    // the heavy values of this bin, with the copies k_rl_strip counted (a bin holds none or a few)
+    {
+        const u32 H = hb1 <= (u32)H_MAX ? hb1 : 0u;
+        for (u32 i = hb0 + tid; i < H; i += BW) {
+            u64 key[KU] = {w.heavy[i]};
+            u32 c[KU] = {w.hcnt[i]};
+            if (c[0] && key[0] != EMPTY) count(key, c, 1u);
         }
     }
+    PHASE_MARK(1);
+    // the bin's segment of every batch: a lane walks the segments of its regions, KU keys at a time
+    for (u32 j = 0; j < w.nb; ++j) {
+        bool any = false;
+        u32 s0[RK], s1[RK];
+#pragma unroll
+        for (int k = 0; k < RK; ++k) {
+            const u32 r = k * BW + tid;
+            s0[k] = s1[k] = 0;
+            if (j < nbt[k] && nbt[k] <= w.nb) {
+                any = true;
+                if (j == 0) {
+                    s0[k] = f0[k];
+                    s1[k] = f1[k];
+                } else {
+                    const u32 *row = w.start + ((size_t)r * w.nb + j) * (P + 1);
+                    s0[k] = row[b];
+                    s1[k] = row[b + 1];
+                }
+                const u64 at = (u64)r * w.region + (u64)j * TBUF;
+                if (s1[k] > (u32)TBUF || s0[k] > s1[k] || at + s1[k] > (u64)w.n) {  // (offsets are checked before they are believed)
+                    atomicOr(&w.ctl->err, ERR_RANGE);
+                    s0[k] = s1[k] = 0;
+                }
+            }
+        }
+        if (j && !__syncthreads_or(any)) break;  // (uniform; round 0 always runs)
+        PHASE_MARK(2);
+        u32 one[KU];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) one[u] = 1u;
+#pragma unroll
+        for (int k = 0; k < RK; ++k) {  // (a segment holds a few keys as a rule, a few dozen where the scores are densest)
+            const u64 *src = w.tail + ((u64)(k * BW + tid) * w.region + (u64)j * TBUF);
+            for (u32 i0 = s0[k]; i0 < s1[k]; i0 += KU) {
+                u64 key[KU];
+#pragma unroll
+                for (int u = 0; u < KU; ++u) key[u] = i0 + u < s1[k] ? src[i0 + u] : 0ull;
+                const u32 left = s1[k] - i0;
+                count(key, one, left < (u32)KU ? left : (u32)KU);
+            }
+        }
+        PHASE_MARK(3);
+    }
     __syncthreads();
-    // (one thread reads the error word for all: another workgroup may be setting it at this moment)
-    if (__syncthreads_or(tid == 0 && (over || w.ctl->err))) {  // more distinct values than a bin holds, or an earlier failure: no index
+    // ---- the occupied sub-ranges in order (their ids), the overflow values in ascending order ----
+    u64 sk[BSL];
+    u32 md = 0;
+#pragma unroll
+    for (int q = 0; q < BSL; ++q) {
+        sk[q] = tk[tid * BSL + q];
+        md += sk[q] != EMPTY ? 1u : 0u;
+    }
+    u32 dm;
+    u32 at = bins_incl_scan<u32>(md, wt32, dm) - md;
+#pragma unroll
+    for (int q = 0; q < BSL; ++q) {
+        if (sk[q] != EMPTY) {
+            if (at < (u32)MAIN_CAP) ids[at] = (unsigned short)(tid * BSL + q);
+            ++at;
+        }
+    }
+    constexpr int OSL = OVS / BW;
+    u64 ok2[OSL];
+    u32 mo = 0;
+#pragma unroll
+    for (int q = 0; q < OSL; ++q) {
+        ok2[q] = ovk[tid * OSL + q];
+        mo += ok2[q] != EMPTY ? 1u : 0u;
+    }
+    u32 no;
+    u32 oat = bins_incl_scan<u32>(mo, wt32, no) - mo;
+#pragma unroll
+    for (int q = 0; q < OSL; ++q) {
+        if (ok2[q] != EMPTY) {
+            if (oat < (u32)OVCAP) {
+                osk[oat] = ok2[q];
+                osc[oat] = ovc[tid * OSL + q];
+            }
+            ++oat;
+        }
+    }
+    const bool bad = dm > (u32)MAIN_CAP || no > (u32)OVCAP;
+    // (one lane reads the error word for all: another workgroup may be setting it at this moment)
+    if (__syncthreads_or(bad || (tid == 0 && (over || w.ctl->err)))) {  // the keys do not suit the index, or an earlier failure
         if (tid == 0) {
-            if (over) atomicOr(&w.ctl->err, ERR_BIN);
+            if (bad || over) atomicOr(&w.ctl->err, ERR_BIN);
             w.bin_d[b] = 0;
             w.bin_c[b] = 0;
             w.bin_w[b] = 0.0;
         }
         return;
     }
-    for (u32 s = tid; s < (u32)BSLOTS; s += WG) {
-        const u64 v = tk[s];
-        if (v != EMPTY) {
-            const u32 p = atomicAdd(&ecnt, 1u);
-            if (p < (u32)CAPD) {
-                ev[p] = v;
-                ec[p] = tc[s];
+    for (u32 i = tid; i < no; i += BW) {  // rank among the overflow values: they are distinct
+        const u64 v = osk[i];
+        u32 rk = 0;
+        for (u32 j2 = 0; j2 < no; ++j2) rk += osk[j2] < v ? 1u : 0u;
+        ovk[rk] = v;  // (the table's own memory: every slot was read before the barrier above)
+        ovc[rk] = osc[i];
+    }
+    __syncthreads();
+    PHASE_MARK(4);
+    // ---- the merged order: a table value's place = table values before it + overflow values below it, and the
+    //      other way round (both lists ascend: two searches; no overflow values: the table's order as it is) ----
+    for (u32 e = tid; e < dm; e += BW) {
+        u32 lo = 0;
+        if (no) {
+            const u64 v = tk[ids[e]];
+            u32 hi = no;  // overflow values below v
+            while (lo < hi) {
+                const u32 mid = (lo + hi) >> 1;
+                if (ovk[mid] < v) lo = mid + 1; else hi = mid;
             }
         }
+        ord[e + lo] = ids[e];
+    }
+    for (u32 i = tid; i < no; i += BW) {
+        const u64 v = ovk[i];
+        u32 lo = 0, hi = dm;  // table values below v
+        while (lo < hi) {
+            const u32 mid = (lo + hi) >> 1;
+            if (tk[ids[mid]] < v) lo = mid + 1; else hi = mid;
+        }
+        ord[lo + i] = (unsigned short)(SUB + i);
     }
     __syncthreads();
-    const u32 d = ecnt < (u32)CAPD ? ecnt : (u32)CAPD;
-    // the values are distinct: rank = number of smaller ones (a bin holds a few hundred values as a rule)
-    for (u32 i = tid; i < d; i += WG) {
-        const u64 v = ev[i];
-        u32 r = 0;
-#pragma unroll 4
-        for (u32 j = 0; j < d; ++j) r += ev[j] < v ? 1u : 0u;
-        tk[r] = v;
-        tc[r] = ec[i];
-    }
-    __syncthreads();
-    // running counts and weights in ascending order: every thread takes `per` consecutive runs
-    const u32 per = (d + WG - 1) / WG;  // <= CAPD / WG = 4
-    const u32 i0 = tid * per < d ? tid * per : d, i1 = i0 + per < d ? i0 + per : d;
-    u64 cs = 0;
-    double ws = 0.0;
-    for (u32 i = i0; i < i1; ++i) {
-        cs += tc[i];
-        ws += (double)tc[i] * exp2(__longlong_as_double((long long)tk[i]) - w.logn);
-    }
-    u64 ctot;
-    double wtotal;
-    u64 cex = wg_excl_scan_t<u64>(cs, wt64, ctot);
-    double wex = wg_excl_scan_t<double>(ws, wtf, wtotal);
+    PHASE_MARK(5);
+    // ---- one pass in ascending order: running copies and weights ----
+    const u32 d = dm + no;
     u64 *rv = w.rval + (size_t)b * CAPD;
     u64 *rc = w.rccum + (size_t)b * CAPD;
     double *rw = w.rwcum + (size_t)b * CAPD;
-    for (u32 i = i0; i < i1; ++i) {
-        cex += tc[i];
-        wex += (double)tc[i] * exp2(__longlong_as_double((long long)tk[i]) - w.logn);
-        rv[i] = tk[i];
-        rc[i] = cex;
-        rw[i] = wex;
+    u64 ccar = 0;
+    double wcar = 0.0;
+    for (u32 p0 = 0; p0 < d; p0 += BW) {
+        const u32 p = p0 + tid;
+        u64 v = 0, c = 0;
+        double wg = 0.0;
+        if (p < d) {
+            const u32 id = ord[p];
+            v = id < (u32)SUB ? tk[id] : ovk[id - SUB];
+            c = id < (u32)SUB ? tc[id] : ovc[id - SUB];
+            wg = (double)c * exp2(__longlong_as_double((long long)v) - w.logn);
+        }
+        u64 ct;
+        double wtt;
+        const u64 ci = bins_incl_scan<u64>(c, wt64, ct);
+        const double wi = bins_incl_scan<double>(wg, wtf, wtt);
+        if (p < d) {
+            rv[p] = v;
+            rc[p] = ccar + ci;
+            rw[p] = wcar + wi;
+        }
+        ccar += ct;
+        wcar += wtt;
     }
     if (tid == 0) {
         w.bin_d[b] = d;
-        w.bin_c[b] = ctot;
-        w.bin_w[b] = wtotal;
+        w.bin_c[b] = ccar;
+        w.bin_w[b] = wcar;
+    }
+    PHASE_MARK(6);
+    if (w.phase && tid == 0) {  // (development aid: the longest workgroup, and when the last one ended)
+        atomicMax(&w.phase[14], t_phase - t_first);
+        atomicMax(&w.phase[15], t_phase);
+        atomicMin(&w.phase[13], ~t_first);  // (~ of the earliest start: the counters are cleared to zero)
     }
 }
 
@@ -874,8 +1219,16 @@ __global__ void __launch_bounds__(256) k_rl_expand(const u64 *__restrict__ vals,
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// development aid: per-phase clock sums (mc_rank_runs_debug_phases)
+__device__ u64 g_phase[16];
+std::atomic<int> g_phase_on{0};
+u64 *phase_ptr() {
+    void *p = nullptr;
+    return hipGetSymbolAddress(&p, HIP_SYMBOL(g_phase)) == hipSuccess ? (u64 *)p : nullptr;
+}
+
 struct RLayout {
-    size_t ctl, heavy, hcnt, nbatch, bin_d, bin_c, bin_w, start, rval, rccum, rwcum, tail, end;
+    size_t ctl, heavy, hcnt, nbatch, rmax, hbin, lut, cell0, bin_d, bin_c, bin_w, start, rval, rccum, rwcum, tail, end;
     u32 region, regions, nb, P;
 };
 
@@ -895,6 +1248,10 @@ RLayout layout_for(u64 n) {
     L.heavy = p; p += align256(H_MAX * sizeof(u64));
     L.hcnt = p; p += align256(H_MAX * sizeof(u32));
     L.nbatch = p; p += align256((size_t)L.regions * sizeof(u32));
+    L.rmax = p; p += align256((size_t)L.regions * sizeof(u64));
+    L.hbin = p; p += align256((P_MAX + 1) * sizeof(u32));
+    L.lut = p; p += align256(CELLS * sizeof(unsigned short));
+    L.cell0 = p; p += align256((P_MAX + 1) * sizeof(unsigned short));
     L.bin_d = p; p += align256(P_MAX * sizeof(u32));
     L.bin_c = p; p += align256(P_MAX * sizeof(u64));
     L.bin_w = p; p += align256(P_MAX * sizeof(double));
@@ -958,6 +1315,10 @@ extern "C" int mc_rank_runs_build(const double *keys_in, uint64_t n, uint64_t n_
     w.in = (const u64 *)keys_in;
     w.tail = (u64 *)(base + L.tail);
     w.nbatch = (u32 *)(base + L.nbatch);
+    w.rmax = (u64 *)(base + L.rmax);
+    w.hbin = (u32 *)(base + L.hbin);
+    w.lut = (unsigned short *)(base + L.lut);
+    w.cell0 = (unsigned short *)(base + L.cell0);
     w.start = (u32 *)(base + L.start);
     w.rval = (u64 *)(base + L.rval);
     w.rccum = (u64 *)(base + L.rccum);
@@ -979,9 +1340,10 @@ extern "C" int mc_rank_runs_build(const double *keys_in, uint64_t n, uint64_t n_
     w.out_wcum = cum_pos;
     w.out_info = (u64 *)info;
     w.out_cap = capacity;
+    w.phase = g_phase_on.load() ? phase_ptr() : nullptr;
     hipLaunchKernelGGL(k_rl_sniff, dim3(1), dim3(SNIFF_THREADS), 0, s, w);
     hipLaunchKernelGGL(k_rl_strip, dim3(L.regions < (u32)STRIP_SLOTS ? L.regions : (u32)STRIP_SLOTS), dim3(WG), 0, s, w);
-    hipLaunchKernelGGL(k_rl_bins, dim3(L.P), dim3(WG), 0, s, w);
+    hipLaunchKernelGGL(k_rl_bins, dim3(L.P), dim3(BW), 0, s, w);
     hipLaunchKernelGGL(k_rl_final, dim3(L.P), dim3(WG), 0, s, w);
     HIP_TRY(hipGetLastError());
     return MC_OK;
@@ -1032,5 +1394,20 @@ extern "C" int mc_rank_runs_expand(const double *vals, const uint64_t *cum_count
                        (const u64 *)vals, (const u64 *)cum_count, cum_pos, (const u64 *)info, (u64)n,
                        std::log2((double)n_global), (u64 *)keys_sorted, positions);
     HIP_TRY(hipGetLastError());
+    return MC_OK;
+}
+
+// Development aid (scripts/runs_prof.py): on != 0 makes the builds that follow add their workgroups' per-phase
+// clock ticks (100 MHz) to 16 device counters; out (may be NULL) receives the counters, which are cleared.
+extern "C" int mc_rank_runs_debug_phases(int on, uint64_t out[16]) {
+    u64 *p = phase_ptr();
+    if (!p) {
+        mc_set_error("mc_rank_runs_debug_phases: no device symbol");
+        return MC_ERR_HIP;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    if (out) HIP_TRY(hipMemcpy(out, p, 16 * sizeof(u64), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(p, 0, 16 * sizeof(u64)));
+    g_phase_on.store(on ? 1 : 0);
     return MC_OK;
 }

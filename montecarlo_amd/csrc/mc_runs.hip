@@ -84,6 +84,7 @@ struct RCtl {
     // the heavy values and the range of one build serve the next builds of as many keys in the same workspace
     u32 list_magic, list_n, list_tail, list_age;
     double map_lo, map_hi;
+    u32 bad_bin, bad_main, bad_over, bad_pad;  // a bin that refused its keys: which, its occupied sub-ranges, its overflow values
 };
 
 struct RWs {
@@ -238,8 +239,9 @@ __global__ void __launch_bounds__(SNIFF_THREADS) k_rl_sniff(RWs w) {
     __shared__ u32 claim[SNIFF_SLOTS / 32];
     __shared__ u64 list[H_MAX];
     __shared__ u64 red[2 * (SNIFF_THREADS / 64)];
-    __shared__ u32 nlist, n_rest;
+    __shared__ u32 nlist;
     __shared__ u32 keep_h, keep_tail, keep_age;
+    __shared__ u64 keep_lo, keep_hi;
     const u32 n = w.n;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (tid == 0) {
@@ -251,10 +253,19 @@ __global__ void __launch_bounds__(SNIFF_THREADS) k_rl_sniff(RWs w) {
         keep_h = ok ? c.n_heavy : 0xFFFFFFFFu;  // (a list of no heavy values is a list too)
         keep_tail = base;
         keep_age = c.list_age + 1;
-        n_rest = 0;
+        keep_lo = (u64)__double_as_longlong(c.map_lo);
+        keep_hi = (u64)__double_as_longlong(c.map_hi);
     }
     __syncthreads();
     u32 keep = keep_h;
+    if (keep != 0xFFFFFFFFu) {
+        // a look at a thousand keys: does the range the hint describes still hold them?  (Keys of another source far
+        // outside it would all fall into the first or the last bin, more than a bin takes: the build would refuse
+        // keys it takes after a search.)
+        const u64 kb = w.in[(u64)tid * (n / SNIFF_THREADS) + (n < (u32)SNIFF_THREADS ? (u32)tid % n : 0u)];
+        const int out = kb < F64_INF && (kb < keep_lo || kb >= keep_hi);
+        if (__syncthreads_count(out) * 4 > SNIFF_THREADS) keep = 0xFFFFFFFFu;
+    }
     if (keep != 0xFFFFFFFFu) {
         int unordered = 0;
         for (u32 i = tid + 1; i < keep; i += SNIFF_THREADS) unordered |= !(w.heavy[i - 1] < w.heavy[i]);
@@ -346,33 +357,23 @@ __global__ void __launch_bounds__(SNIFF_THREADS) k_rl_sniff(RWs w) {
             }
         }
     }
-    // the range of the keys that are not heavy (finite ones; all finite sample keys when those are too few to tell)
-    for (int pass = 0; pass < 2; ++pass) {
+    // the range of the sample's finite keys, heavy ones included (the next build asks of its keys whether this
+    // range still holds them, and most keys are copies of heavy values)
+    {
         u64 mn = EMPTY, mx = 0;
-        u32 cnt = 0;
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
-            if (have[q] && k[q] < F64_INF && (pass == 1 || !over[q])) {
+            if (have[q] && k[q] < F64_INF) {
                 mn = k[q] < mn ? k[q] : mn;
                 mx = k[q] > mx ? k[q] : mx;
-                ++cnt;
             }
         }
         mn = wave_min(mn);
         mx = wave_max(mx);
-#pragma unroll
-        for (int o = 32; o; o >>= 1) cnt += __shfl_xor(cnt, o);
-        __syncthreads();
         if (lane == 0) {
             red[wid] = mn;
             red[SNIFF_THREADS / 64 + wid] = mx;
-            if (cnt) atomicAdd(&n_rest, cnt);
         }
-        __syncthreads();
-        if (n_rest >= 64u || pass == 1) break;  // (uniform)
-        __syncthreads();
-        if (tid == 0) n_rest = 0;
-        __syncthreads();
     }
     __syncthreads();
     const u32 H = nlist;
@@ -1010,7 +1011,13 @@ __global__ void __launch_bounds__(BW) k_rl_bins(RWs w) {
     // (one lane reads the error word for all: another workgroup may be setting it at this moment)
     if (__syncthreads_or(bad || (tid == 0 && (over || w.ctl->err)))) {  // the keys do not suit the index, or an earlier failure
         if (tid == 0) {
-            if (bad || over) atomicOr(&w.ctl->err, ERR_BIN);
+            if (bad || over) {
+                if (!(atomicOr(&w.ctl->err, ERR_BIN) & ERR_BIN)) {  // (the first bin to refuse tells why)
+                    w.ctl->bad_bin = b;
+                    w.ctl->bad_main = dm;
+                    w.ctl->bad_over = no > nov ? no : nov;
+                }
+            }
             w.bin_d[b] = 0;
             w.bin_c[b] = 0;
             w.bin_w[b] = 0.0;
@@ -1137,8 +1144,8 @@ __global__ void __launch_bounds__(WG) k_rl_final(RWs w) {
         w.out_info[3] = w.ctl->n_heavy;
         w.out_info[4] = w.ctl->n_tail;
         w.out_info[5] = w.ctl->list_age;
-        w.out_info[6] = 0;
-        w.out_info[7] = 0;
+        w.out_info[6] = e & ERR_BIN ? ((u64)w.ctl->bad_bin << 32) | w.P : 0ull;
+        w.out_info[7] = e & ERR_BIN ? ((u64)w.ctl->bad_main << 32) | w.ctl->bad_over : 0ull;
     }
     if (err) return;
     const u32 d = w.bin_d[b] <= (u32)CAPD ? w.bin_d[b] : 0u;

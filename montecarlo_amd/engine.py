@@ -187,39 +187,141 @@ class DeviceModel:
         return ml2p, lens, syms
 
 
+class RunsBuffers:
+    """Outputs and workspace of one run-length rank build of up to ``n`` keys (mc_rank_runs_build), for callers that
+    build again and again without allocating: ``DeviceRank(keys, runs=buffers)``."""
+
+    def __init__(self, n: int, device):
+        self.n = int(n)
+        self.tdev = torch.device(device)
+        with torch.cuda.device(self.tdev):
+            self.capacity = int(nv.lib.mc_rank_runs_capacity(self.n))
+            self.vals = torch.empty(self.capacity, dtype=torch.float64, device=self.tdev)
+            self.cum_count = torch.empty(self.capacity, dtype=torch.int64, device=self.tdev)
+            self.cum_pos = torch.empty(self.capacity, dtype=torch.float64, device=self.tdev)
+            self.info = torch.zeros(8, dtype=torch.int64, device=self.tdev)
+            self.ws = torch.empty(max(1, nv.lib.mc_rank_runs_workspace_bytes(self.n)), dtype=torch.uint8, device=self.tdev)
+            # (memory fresh from the allocator may hold anything, another build's hint included: start clean)
+            nv.check(nv.lib.mc_rank_runs_forget(_vp(self.ws), self.n, C.c_void_p(torch.cuda.current_stream(self.tdev).cuda_stream)))
+
+
+def runs_index_wanted(n: int) -> bool:
+    """The run-length index is the default wherever it applies; MC_RANK_INDEX=sorted keeps the expanded arrays."""
+    import os
+    return 0 < n <= int(nv.lib.mc_rank_runs_max_keys()) and os.environ.get("MC_RANK_INDEX", "runs") != "sorted"
+
+
 class DeviceRank:
-    """Sorted keys + positions on one GPU (MonteCarloLib.__init__, lib4mc/MonteCarloLib.py:10-28)."""
+    """The rank index of sampled keys on one GPU (MonteCarloLib.__init__, lib4mc/MonteCarloLib.py:10-28).
+
+    ``index="runs"`` (the default where it applies): one entry per distinct value -- value, samples at or below
+    it, summed weights at or below it (mc_rank_runs_build) -- which is all ``bisect_right`` ever reads; the sorted
+    keys and the positions are written only when somebody looks at ``keys_sorted`` / ``positions``.  Keys that do
+    not repeat do not suit that index (mc_rank_runs_check says so): the build then falls back to
+    ``index="sorted"``, the expanded arrays of mc_rank_build, which sort anything.  A caller that brings its own
+    buffers (``runs=`` or ``keys_sorted=`` / ``positions=``) decides the kind by that and checks the build itself
+    (``check()``): nothing waits for the GPU here."""
 
     def __init__(self, keys: torch.Tensor, n_global: Optional[int] = None, workspace: torch.Tensor = None,
-                 keys_sorted: torch.Tensor = None, positions: torch.Tensor = None):
+                 keys_sorted: torch.Tensor = None, positions: torch.Tensor = None, runs: "RunsBuffers" = None,
+                 index: str = None):
         _require_gpu()
         assert keys.is_cuda and keys.dtype == torch.float64 and keys.is_contiguous()
         self.n = keys.numel()
         self.n_global = self.n if n_global is None else int(n_global)
         self.tdev = keys.device
+        self._keys_in = keys
+        self._sorted = keys_sorted
+        self._positions = positions
+        self._ws = workspace
+        self.runs = None
+        own_buffers = keys_sorted is not None or positions is not None or workspace is not None
+        if index is None:
+            index = "runs" if runs is not None or (not own_buffers and runs_index_wanted(self.n)) else "sorted"
+        if index == "runs" and self.n:
+            self.runs = runs if runs is not None else RunsBuffers(self.n, self.tdev)
+            assert self.runs.n >= self.n and self.runs.tdev == self.tdev
+            self._build_runs()
+            if runs is None:                                  # the library's own buffers: settle the kind now
+                rc = self._runs_status()[0]
+                if rc == nv.ERR_UNSUITED:
+                    self.runs = None                          # keys that do not repeat: the expanded arrays sort anything
+                else:
+                    nv.check(rc)
+        if self.runs is None:
+            self._build_sorted()
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.tdev).cuda_stream)
+
+    def _build_runs(self):
+        r = self.runs
+        with torch.cuda.device(self.tdev):
+            nv.check(nv.lib.mc_rank_runs_build(_vp(self._keys_in), self.n, self.n_global, _vp(r.vals), _vp(r.cum_count),
+                                               _vp(r.cum_pos), r.capacity, _vp(r.info), _vp(r.ws), r.ws.numel(),
+                                               self._stream()))
+
+    def _runs_status(self):
+        h = (C.c_uint64 * 8)()
+        with torch.cuda.device(self.tdev):
+            rc = nv.lib.mc_rank_runs_check(_vp(self.runs.info), self._stream(), h)
+        return rc, list(h)
+
+    def _build_sorted(self):
+        keys = self._keys_in
         with torch.cuda.device(self.tdev):
             need = nv.lib.mc_rank_workspace_bytes(self.n)
-            ws = workspace if workspace is not None else torch.empty(need, dtype=torch.uint8, device=self.tdev)
-            self.keys_sorted = keys_sorted if keys_sorted is not None else torch.empty_like(keys)
-            self.positions = positions if positions is not None else torch.empty_like(keys)
-            stream = C.c_void_p(torch.cuda.current_stream(self.tdev).cuda_stream)
-            if workspace is None and self.n:
+            fresh = self._ws is None
+            ws = self._ws if self._ws is not None else torch.empty(need, dtype=torch.uint8, device=self.tdev)
+            if self._sorted is None:
+                self._sorted = torch.empty_like(keys)
+            if self._positions is None:
+                self._positions = torch.empty_like(keys)
+            if fresh and self.n:
                 # (a caller's workspace carries the list of heavy values from one build to the next, include/mi355mc.h;
                 # memory fresh from the allocator may hold anything, another build's list included: start clean)
-                nv.check(nv.lib.mc_workspace_forget(_vp(ws), self.n, stream))
-            nv.check(nv.lib.mc_rank_build(_vp(keys), self.n, self.n_global, _vp(self.keys_sorted),
-                                          _vp(self.positions), _vp(ws), ws.numel(),
-                                          C.c_void_p(torch.cuda.current_stream(self.tdev).cuda_stream)))
+                nv.check(nv.lib.mc_workspace_forget(_vp(ws), self.n, self._stream()))
+            nv.check(nv.lib.mc_rank_build(_vp(keys), self.n, self.n_global, _vp(self._sorted), _vp(self._positions),
+                                          _vp(ws), ws.numel(), self._stream()))
             self._ws = ws
 
+    def _expand(self):
+        """The reference's two arrays from the runs, for callers that look at them."""
+        if self._sorted is None or self._positions is None:
+            with torch.cuda.device(self.tdev):
+                srt = torch.empty(self.n, dtype=torch.float64, device=self.tdev)
+                pos = torch.empty(self.n, dtype=torch.float64, device=self.tdev)
+                r = self.runs
+                nv.check(nv.lib.mc_rank_runs_expand(_vp(r.vals), _vp(r.cum_count), _vp(r.cum_pos), _vp(r.info), self.n,
+                                                    self.n_global, _vp(srt), _vp(pos), self._stream()))
+            self._sorted, self._positions = srt, pos
+
+    @property
+    def keys_sorted(self) -> torch.Tensor:
+        if self.runs is not None:
+            self._expand()
+        return self._sorted
+
+    @property
+    def positions(self) -> torch.Tensor:
+        if self.runs is not None:
+            self._expand()
+        return self._positions
+
     def check(self) -> dict:
-        """Synchronise and read the build's status (mc_rank_check): raises if the sort failed on the device
-        (positions are NaN then); returns the sort's counters."""
+        """Synchronise and read the build's status: raises if it failed on the device (positions are NaN then);
+        returns the build's counters."""
+        if self.runs is not None:
+            rc, h = self._runs_status()
+            out = dict(zip(("distinct_values", "error", "keys_counted", "heavy_values", "tail_keys", "list_age"), h))
+            out["index"] = "runs"
+            nv.check(rc)
+            return out
         info = (C.c_uint64 * 8)()
         with torch.cuda.device(self.tdev):
-            rc = nv.lib.mc_rank_check(_vp(self._ws), self.n,
-                                      C.c_void_p(torch.cuda.current_stream(self.tdev).cuda_stream), info)
+            rc = nv.lib.mc_rank_check(_vp(self._ws), self.n, self._stream(), info)
         out = dict(zip(("error", "heavy_values", "tail_keys", "levels", "finish_tiles", "segments", "list_age"), list(info)))
+        out["index"] = "sorted"
         nv.check(rc)
         return out
 
@@ -230,8 +332,16 @@ class DeviceRank:
         with torch.cuda.device(self.tdev):
             pos = out_pos if out_pos is not None else torch.empty(t, dtype=torch.float64, device=self.tdev)
             cnt = out_cnt if out_cnt is not None else torch.empty(t, dtype=torch.int64, device=self.tdev)
-            nv.check(nv.lib.mc_rank_query(_vp(self.keys_sorted), _vp(self.positions), self.n, _vp(x), t, _vp(pos),
-                                          _vp(cnt), C.c_void_p(torch.cuda.current_stream(self.tdev).cuda_stream)))
+            if self.runs is not None:
+                r = self.runs
+                nv.check(nv.lib.mc_rank_runs_query(_vp(r.vals), _vp(r.cum_count), _vp(r.cum_pos), _vp(r.info), _vp(x), t,
+                                                   _vp(pos), _vp(cnt), self._stream()))
+            elif self.n == 0:
+                pos.zero_()
+                cnt.zero_()
+            else:
+                nv.check(nv.lib.mc_rank_query(_vp(self._sorted), _vp(self._positions), self.n, _vp(x), t, _vp(pos),
+                                              _vp(cnt), self._stream()))
         return pos, cnt
 
 

@@ -2,8 +2,10 @@
 (lib4mc/MonteCarloLib.py:9-68): the sampled -log2 p are sorted, turned into the
 running sum of 1/(n*p), and a test password's -log2 p is bisected into it.
 
-Here the sort (radix), the running sum (prefix scan) and the bisection (one lane
-per test password) are HIP kernels; keys and positions stay on the GPU.  With
+Here the index (one entry per distinct sampled value: the value, the samples at or
+below it, their summed weights -- all that bisect_right ever reads; or, for keys
+that do not repeat, the sorted keys and their prefix sums) and the bisection (one
+lane per test password) are HIP kernels; keys and positions stay on the GPU.  With
 ``group`` (a torch.distributed process group) the instance holds one shard of
 the samples and queries all-reduce the per-shard partial sums.
 """
@@ -36,7 +38,8 @@ class MonteCarloLib:
         self.__rank = DeviceRank(keys, n_global=n_global)
         # the reference sorts the caller's list in place (:11); keep that side effect
         if isinstance(minus_log_prob_list, SampleKeys):
-            minus_log_prob_list._replace(self.__rank.keys_sorted)
+            rank = self.__rank
+            minus_log_prob_list._replace(lambda: rank.keys_sorted)
         elif isinstance(minus_log_prob_list, list):
             minus_log_prob_list[:] = self.__rank.keys_sorted.cpu().numpy().tolist()
         self.__gc = None

@@ -44,13 +44,19 @@ class SampleKeys(collections.abc.Sequence):
     10^7..10^10 keys cannot be a Python list."""
 
     def __init__(self, tensor, group=None, n_global: int = None):
-        self.tensor = tensor
+        self._tensor, self._later, self._len = tensor, None, int(tensor.numel())
         self._host = None
         # sharded sampling (montecarlo_amd.dist.use_group): this rank's share of n_global keys
         self.group, self.n_global = group, n_global
 
+    @property
+    def tensor(self):
+        if self._later is not None:                          # (the sorted keys, written when somebody looks)
+            self._tensor, self._later = self._later(), None
+        return self._tensor
+
     def __len__(self):
-        return int(self.tensor.numel())
+        return self._len
 
     def _materialise(self):
         if self._host is None:
@@ -68,7 +74,12 @@ class SampleKeys(collections.abc.Sequence):
         return self._materialise().tolist()
 
     def _replace(self, tensor):
-        self.tensor, self._host = tensor, None
+        """``tensor``: the new keys, or a function that returns them (MonteCarloLib sorts this list "in place";
+        with the run-length index the sorted array only exists once it is asked for)."""
+        if callable(tensor):
+            self._tensor, self._later, self._host = None, tensor, None
+        else:
+            self._tensor, self._later, self._host = tensor, None, None
 
 
 class MonteCarlo(metaclass=abc.ABCMeta):

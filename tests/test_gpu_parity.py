@@ -578,14 +578,17 @@ def test_scoring_hash_path_equals_dense_path(big_model):
     assert np.array_equal(a.cpu().numpy().view(np.uint64), cm.score(test).view(np.uint64))
 
 
-def test_rank_pipeline_full_size(big_model):
+@pytest.mark.parametrize("index", ["runs", "sorted"])
+def test_rank_pipeline_full_size(big_model, index):
     """config-2 sizes: 1e7 samples, 1e6 queries -- size-independent properties plus an
-    independent device sort (torch.sort) and a CPU prefix sum on a stride."""
+    independent device sort (torch.sort) and a CPU prefix sum on a stride; with the run-length index (the
+    default: the sorted keys and positions are written from the runs when looked at) and with the expanded arrays."""
     m, cm = big_model
     n = 10_000_000
     keys = m._dev.sample(n, 99)["ml2p"]
     m._dev.check()
-    rk = DeviceRank(keys)
+    rk = DeviceRank(keys, index=index)
+    assert (rk.runs is not None) == (index == "runs") and rk.check()["error"] == 0
     srt, _ = torch.sort(keys)
     assert torch.equal(rk.keys_sorted.view(torch.int64), srt.view(torch.int64))
     pos = rk.positions
@@ -603,10 +606,13 @@ def test_rank_pipeline_full_size(big_model):
     cnt = torch.searchsorted(srt, x, right=True)
     assert torch.equal(qc, cnt)
     want = torch.where(cnt > 0, pos[(cnt - 1).clamp(min=0)], torch.zeros_like(x))
-    assert torch.equal(qp.view(torch.int64), want.view(torch.int64))
+    if index == "sorted":
+        assert torch.equal(qp.view(torch.int64), want.view(torch.int64))
+    else:                                                   # (the runs' own sums; the arrays are written from them)
+        assert bool(((qp - want).abs() <= REL * want).all())
     # against the C oracle's sequential prefix sum on a subsample of 2e5 keys
     sub = keys[:200000].contiguous()
-    rs = DeviceRank(sub)
+    rs = DeviceRank(sub, index=index)
     osrt, opos = c_oracle.rank_build(sub.cpu().numpy())
     assert np.array_equal(rs.keys_sorted.cpu().numpy().view(np.uint64), osrt.view(np.uint64))
     assert np.all(np.abs(rs.positions.cpu().numpy() - opos) <= REL * opos)
@@ -789,7 +795,7 @@ def test_rank_large_search_for_heavy_values(big_model):
         for mode in (1, 2):
             nv.lib.mc_rank_debug_search(mode)
             try:
-                rk = DeviceRank(keys)
+                rk = DeviceRank(keys, index="sorted")
                 info = rk.check()
             finally:
                 nv.lib.mc_rank_debug_search(0)
@@ -803,7 +809,7 @@ def test_rank_large_search_for_heavy_values(big_model):
     assert found["2500 values"][0] > 2000 and found["all distinct"] == (0, 0) and found["one value"] == (1, 1)
     n = (1 << 26) + 77                                                      # by size
     keys = m._dev.sample(n, 9)["ml2p"]
-    rk = DeviceRank(keys)
+    rk = DeviceRank(keys, index="sorted")
     info = rk.check()
     assert info["error"] == 0 and info["heavy_values"] > 1024
     assert torch.equal(rk.keys_sorted.view(torch.int64), torch.sort(keys.view(torch.int64))[0])
@@ -824,7 +830,7 @@ def test_sort_and_order_fuzz():
         n = int(10 ** (torch.rand(1, generator=g).item() * 6.5)) + 1
         x, kind = fz.make(g, n)
         xd = x.cuda()
-        rk = DeviceRank(xd)
+        rk = DeviceRank(xd, index="sorted")
         assert rk.check()["error"] == 0
         assert torch.equal(rk.keys_sorted.view(torch.int64), torch.sort(xd.view(torch.int64))[0]), (c, kind, n)
         srt, order = device_order(xd)
@@ -922,7 +928,7 @@ def golden_path(name):
     return os.path.join(GOLDEN, name)
 
 
-def test_rank_build_failure_path_is_loud_and_stays_inside_its_buffers():
+def test_rank_build_failure_path_is_loud_and_stays_inside_its_buffers(monkeypatch):
     """The device-side failure path of mc_rank_build, on demand (mc_rank_debug_fail: the sort's tables
     "overflow" at the first plan): nothing is written outside keys_sorted / positions / workspace (canaries either
     side of each), keys_in is untouched, positions are NaN, mc_rank_check reports it, DeviceRank.check and the
@@ -959,11 +965,13 @@ def test_rank_build_failure_path_is_loud_and_stays_inside_its_buffers():
         assert rc == -6 and info[0] != 0 and b"failed on the device" in nv.lib.mc_last_error()
         assert bool(torch.isnan(pos).all())
         assert canaries_intact() and torch.equal(keys, keys_before)
-        rk = DeviceRank(keys)                                      # the host classes surface it
+        rk = DeviceRank(keys, index="sorted")                      # the host classes surface it
         with pytest.raises(nv.NativeError, match="failed on the device"):
             rk.check()
+        monkeypatch.setenv("MC_RANK_INDEX", "sorted")              # (the knob fails mc_rank_build, not the run index)
         with pytest.raises(RuntimeError, match="NaN"):
             MonteCarloLib(keys).ml2p2rank(20.0)
+        monkeypatch.delenv("MC_RANK_INDEX")
     finally:
         nv.lib.mc_rank_debug_fail(0)
     build()

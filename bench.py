@@ -3,7 +3,8 @@
 (threshold 10) trained on 100k synthetic Zipfian passwords; one "step" = the whole
 guess-number hot path on one GPU:
 
-    sample N=1e7 strings (k_sample) -> sort + prefix sum of 1/(n p) (mc_rank_build)
+    sample N=1e7 strings (k_sample) -> rank index: per distinct -log2 p its samples and the sum of 1/(n p) up to it
+       (mc_rank_runs_build: all bisect_right ever reads; --rank-index sorted: the reference's two arrays, mc_rank_build)
     -> score T=1e6 test passwords (k_score) -> their stable order by -log2 p (mc_order_keys)
     -> bisect them into the curve (k_query)
     [-> all-reduce of the per-test partial sums when world_size > 1 (in the step's order; --overlap-comm puts
@@ -24,6 +25,7 @@ launch through torch.distributed.run (one rank per GPU, weak scaling: every GPU 
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -38,7 +40,7 @@ os.environ.setdefault("TQDM_DISABLE", "1")
 
 from montecarlo_amd import synth  # noqa: E402
 from montecarlo_amd.backwords_simulator import BackWordsMonteCarlo  # noqa: E402
-from montecarlo_amd.engine import DeviceRank, device_guess_numbers, device_order  # noqa: E402
+from montecarlo_amd.engine import DeviceRank, RunsBuffers, device_guess_numbers, device_order  # noqa: E402
 from montecarlo_amd import _native as nv  # noqa: E402
 from montecarlo_amd import dist as mcd  # noqa: E402
 
@@ -67,9 +69,20 @@ except (OSError, ValueError):
 # from the compare counter: an upper bound, single-threshold buckets compare without a read),
 # 8 B key written per sample.  All counts come from the device counters of the timed launches.
 B_DRAW, B_INDIRECT, B_PROBE, B_SAMPLE = 16, 16, 8, 8
-# rank build, algorithmic minimum: every key read once and written once in order (16 B),
-# weight sums read it again (8 B), positions read it and write the running sum (16 B)
-B_RANK = 40
+# rank build.  Run-length index (the default): ONE read of the keys (8 B a key) + 24 B written per
+# distinct value.  Expanded arrays (--rank-index sorted): every key read once and written once in order (16 B), weight
+# sums read it again (8 B), positions read it and write the running sum (16 B)
+B_RANK_RUNS_KEY, B_RANK_RUNS_VALUE, B_RANK = 8, 24, 40
+
+
+def C_vp(t):
+    import ctypes as C
+    return C.c_void_p(t.data_ptr())
+
+
+def C_stream(dev):
+    import ctypes as C
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
 def first_id(it: int, world: int, rank: int, n: int) -> int:
@@ -104,6 +117,10 @@ def main():
     ap.add_argument("--tests", type=int, default=1_000_000)
     ap.add_argument("--train-lines", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rank-index", choices=("runs", "sorted"), default="runs",
+                    help="`runs` (default): the run-length rank index (mc_rank_runs_build: value, samples and summed "
+                         "weights per distinct -log2 p; one read of the keys); `sorted`: the reference's sorted keys "
+                         "and positions in full (mc_rank_build)")
     ap.add_argument("--second-stream", action="store_true", help=argparse.SUPPRESS)  # (the default)
     ap.add_argument("--serial", action="store_true",
                     help="everything on one stream in the step's own order (0.98 ms a step). Default: the test set is "
@@ -131,6 +148,12 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="rehearsal of the multi-rank control flow on a 1-GPU box: every rank uses cuda:0 and the "
                          "collective runs over gloo (the printed numbers mean nothing)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the legs after the timed region that run BASELINE configs 3, 4, 5 and the sub-word "
+                         "scorer once at their per-GPU sizes (`other_configs` in the JSON line; about a minute)")
+    ap.add_argument("--dump-last", default="",
+                    help="rank 0 writes what the host received from the last timed step (guess numbers, how many of "
+                         "them fit int64, order, sorted scores) to this .npz (tests/test_gpu_bench_modes.py)")
     ap.add_argument("--cpu-samples", type=int, default=0,
                     help="samples of the CPU baseline leg (default: the whole workload, about 10-20 s of one core)")
     args = ap.parse_args()
@@ -175,6 +198,7 @@ def main():
     keys_sorted = torch.empty_like(keys)
     positions = torch.empty_like(keys)
     ws = torch.empty(nv.lib.mc_rank_workspace_bytes(N), dtype=torch.uint8, device=dev)
+    runs_buf = RunsBuffers(N, dev) if args.rank_index == "runs" else None
     t_ml2p = torch.empty(T, dtype=torch.float64, device=dev)
     # two sets of result buffers, a stream of its own for the collective and one for the copies to the host:
     # a step's all-reduce (world > 1) runs beside the next step's SAMPLING and the main stream waits for it
@@ -249,7 +273,10 @@ def main():
             if done is not None:
                 main_stream.wait_event(done)
                 reduced[i] = None
-        rk = DeviceRank(keys, n_global=N * world, workspace=ws, keys_sorted=keys_sorted, positions=positions)
+        if runs_buf is not None:
+            rk = DeviceRank(keys, n_global=N * world, runs=runs_buf)
+        else:
+            rk = DeviceRank(keys, n_global=N * world, workspace=ws, keys_sorted=keys_sorted, positions=positions)
         rk_last[0] = rk
         marks[2].record()
         if side is None:
@@ -346,8 +373,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    first_step_ms = None
     for w in range(args.warmup):
+        if w == 0:                                          # the very first step of the process, alone and waited for
+            torch.cuda.synchronize()
+            t_first = time.perf_counter()
         step(w, False)
+        if w == 0:
+            torch.cuda.synchronize()
+            first_step_ms = (time.perf_counter() - t_first) * 1e3
     torch.cuda.synchronize()
     dm.check()                                              # clears counters; raises on a diverged sample
     fence()
@@ -364,8 +398,16 @@ def main():
         dt = float(tmax.item())
     cnt = dm.check()
     ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
+    if carry_mode:
+        ms["d2h"] = None                                    # (carried in the sampling launch: inside `sample`)
 
-    # sanity on the last step (not timed): finite keys, sorted output
+    # sanity on the last step (not timed): finite keys, sorted output (run index: the arrays written from the runs)
+    sort_info = rk_last[0].check()
+    if runs_buf is not None:
+        keys_sorted, positions = rk_last[0].keys_sorted, rk_last[0].positions
+        D = sort_info["distinct_values"]
+        assert sort_info["keys_counted"] == N and 0 < D <= N
+        assert bool((runs_buf.vals[1:D] > runs_buf.vals[:D - 1]).all()) and int(runs_buf.cum_count[D - 1]) == N
     assert bool(torch.isfinite(keys).all()) and bool((keys_sorted[1:] >= keys_sorted[:-1]).all())
     assert bool(torch.isfinite(positions).all()) and bool((positions[1:] >= positions[:-1]).all())
 
@@ -387,7 +429,29 @@ def main():
     last = host[(args.warmup + args.steps - 1) & 1]
     assert np.array_equal(np.sort(last["order"].numpy().view(np.uint32)), np.arange(T, dtype=np.uint32))
     assert np.array_equal(t_ml2p.cpu().numpy()[last["order"].numpy().view(np.uint32)], last["ml2p"].numpy())
-    sort_info = rk_last[0].check()
+
+    if args.dump_last and rank == 0:
+        np.savez(args.dump_last, rank=last["rank"].numpy(), exact=last["exact"].numpy(), order=last["order"].numpy(),
+                 ml2p=last["ml2p"].numpy())
+
+    # ---- what the host received from THIS arrangement of streams against a serial recompute and the C oracle ----
+    arrangement = check_arrangement(args, dm, model, flat, host, t_ml2p, d_syms, d_off, N, T, world, rank, seed, dev) \
+        if world == 1 else None
+
+    # ---- one cold step: no hint from earlier steps in any workspace, alone on the GPU, waited for ----
+    cold_step_ms = None
+    if world == 1:
+        if runs_buf is not None:
+            nv.check(nv.lib.mc_rank_runs_forget(C_vp(runs_buf.ws), N, C_stream(dev)))
+        else:
+            nv.check(nv.lib.mc_workspace_forget(C_vp(ws), N, C_stream(dev)))
+        nv.check(nv.lib.mc_workspace_forget(C_vp(ws_order), T, C_stream(dev)))
+        torch.cuda.synchronize()
+        t_c = time.perf_counter()
+        step(args.warmup + args.steps, False)
+        flush_carry()
+        torch.cuda.synchronize()
+        cold_step_ms = (time.perf_counter() - t_c) * 1e3
 
     # the sampling launch with the GPU to itself (the library's own geometry, nothing carried, no second stream):
     # 50 launches after the timed region, for the roofline line beside the in-step figure
@@ -410,7 +474,8 @@ def main():
         if carry_mode:                                      # the launch also reads and writes the previous result set
             bytes_per_launch += 2 * 8 * TB
         achieved = bytes_per_launch / (ms["sample"] * 1e-3) / 1e9
-        rank_bytes = N * B_RANK
+        rank_bytes = (N * B_RANK_RUNS_KEY + sort_info["distinct_values"] * B_RANK_RUNS_VALUE) if runs_buf is not None \
+            else N * B_RANK
         gn_ms = ms["score"] + ms["order"] + ms["query"] + ms["guess_numbers"]
         rank_achieved = rank_bytes / (ms["rank"] * 1e-3) / 1e9
         out = {
@@ -423,11 +488,19 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[1]: backwords char-level backoff (threshold 10, 100k synthetic Zipf "
                                    "training lines), 1e7 samples + 1e6 test pwds per GPU per step",
-                       "sort": "csrc/mc_sort.hip (heavy values counted, MSD radix on the rest, in-LDS finish; no "
-                               "workgroup waits for another)",
+                       "rank_index": ("csrc/mc_runs.hip: run-length index (value, samples, summed weights per distinct "
+                                      "-log2 p; heavy values counted in LDS, the rest ordered by value range batch by "
+                                      "batch and counted per range; no workgroup waits for another)"
+                                      if runs_buf is not None else
+                                      "csrc/mc_sort.hip: sorted keys + positions in full (heavy values counted, MSD radix "
+                                      "on the rest, in-LDS finish; no workgroup waits for another)"),
                        "samples_per_gpu": N, "test_pwds": T, "contexts": int(flat.info[nv.INFO_NCTX]),
                        "entries": int(flat.info[nv.INFO_NENT]), "table_bytes": int(flat.info[nv.INFO_DEVICE_BYTES])},
             "stage_ms": ms, "test_set_on_second_stream": side is not None,
+            # one step alone and waited for: the first of the process (code objects load, allocator warms up) and one
+            # after the timed region with every workspace's hint forgotten (what ONE estimate costs a caller)
+            "first_step_ms": first_step_ms, "cold_step_ms": cold_step_ms,
+            "arrangement_check": arrangement,
             "stage_ms_note": ("score and order run on a second stream beside sample and rank (their times include "
                               "waiting for free slots); the step is sample + rank + query + guess_numbers"
                               if side is not None else "one stream: the step is the sum of the stages"),
@@ -462,19 +535,232 @@ def main():
                                    / HBM_PEAK_GBS,
                                    "what": "50 launches of the same 1e7 samples after the timed region, GPU to itself, "
                                            "the library's default geometry (14 workgroups a CU), nothing carried"}},
-            # the rank build as a whole (csrc/mc_sort.hip's launches + weight sums + positions, timed together)
-            # against the 40 B/key a sort-and-scan cannot do without
-            "roofline_rank_build": {"bound": "hbm", "kernel": "mc_rank_build (k_sniff, k_strip, k_scatter, k_count, "
-                                    "k_deep, k_finish, k_fill, k_weight_sums, k_positions)", "achieved": rank_achieved,
+            # the rank build as a whole, timed together: the run index against ONE read of the keys + 24 B per
+            # distinct value; the expanded arrays against the 40 B/key a sort-and-scan cannot do without
+            "roofline_rank_build": {"bound": "hbm", "kernel": "mc_rank_runs_build (k_rl_sniff, k_rl_strip, k_rl_bins, "
+                                    "k_rl_final)" if runs_buf is not None else "mc_rank_build (k_sniff, k_strip, "
+                                    "k_scatter, k_count, k_deep, k_finish, k_fill, k_weight_sums, k_positions)",
+                                    "achieved": rank_achieved,
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rank_achieved / HBM_PEAK_GBS,
                                     "traffic": TRAFFIC.get("mc_rank_build"), "bytes_per_launch": rank_bytes,
                                     "kernel_ms": ms["rank"], "sort": sort_info},
         }
+        if not args.no_other_configs and world == 1 and N >= 1_000_000:
+            del keys, keys_sorted, positions, ws                   # (the legs below bring their own buffers)
+            torch.cuda.empty_cache()
+            out["other_configs"] = other_configs(dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, test, args.cpu_samples or N)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def check_arrangement(args, dm, model, flat, host, t_ml2p, d_syms, d_off, N, T, world, rank, seed, dev):
+    """The guess numbers the host received from the LAST timed step -- through this run's arrangement of streams, the
+    carried copy and the reused workspaces -- against (a) the same step computed again on one stream with fresh
+    buffers from the same sample ids: order and sorted scores equal bit for bit, guess numbers equal (bit for bit with
+    --rank-index sorted; with the run index, whose sums follow the build's own bins, within 1e-9 -- in practice one
+    ulp of the float64 position -- and at most 2 of those below 2^50 off by one where ceil() sits on an integer); (b) on a cut of 2e5
+    samples and 3e4 test passwords, the C oracle's ranks (reference lib4mc/MonteCarloLib.py:34-58): within 1e-9, and
+    at most 2 guess numbers differing where ceil() sits on an exact integer."""
+    from oracle import c_oracle
+    it = args.warmup + args.steps - 1
+    got = host[it & 1]
+    first = first_id(it, world, rank, N)
+    keys = dm.sample(N, seed, first_id=first)["ml2p"]
+    rk = DeviceRank(keys, n_global=N * world, index=args.rank_index)
+    sc = dm.score_device(d_syms, d_off, T)
+    srt, order = device_order(sc)
+    pos, cnt = rk.query(srt)
+    ranks, exact, _ = device_guess_numbers(pos, cnt, True)
+    torch.cuda.synchronize()
+    # order and sorted scores do not depend on the samples: bit for bit.  Guess numbers: with the expanded arrays bit
+    # for bit; the run index sums a value range's weights in the order of ITS bins, which follow the sample a build
+    # (or the build whose hint it took) looked at: positions agree to ~1e-15 and a guess number may differ where
+    # ceil() sits on an exact integer
+    same_order = bool(torch.equal(order.cpu(), got["order"]) and
+                      torch.equal(srt.cpu().view(torch.int64), got["ml2p"].view(torch.int64)))
+    k = int(exact.item())
+    a, b = ranks.cpu().numpy()[:k], got["rank"].numpy()[:k]
+    differing = int(np.sum(a != b))
+    # (a guess number beyond 2^50 is a rounded float64 position: one ulp of the sum IS a different integer there)
+    small = b < (1 << 50)
+    differing_small = int(np.sum(a[small] != b[small]))
+    rel_gn = float(np.max(np.abs(a - b) / np.maximum(b, 1))) if k else 0.0
+    res = {"order_and_scores_bit_identical": same_order, "exact_count_equal": k == int(got["exact"][0]),
+           "guess_numbers_compared": k, "guess_numbers_differing_from_serial_recompute": differing,
+           "of_them_below_2^50": differing_small, "guess_numbers_max_rel_diff": rel_gn}
+    assert same_order and res["exact_count_equal"], "the step's arrangement of streams changed what the host received"
+    assert rel_gn <= 1e-9 and (differing_small <= 2 if args.rank_index == "runs" else differing == 0), res
+    # the C oracle on a cut: its own samples (same Philox ids), rank build, scores, order, bisection, ranks
+    n_cut, t_cut = min(N, 200_000), min(T, 30_000)
+    cm = c_oracle.COracleModel(model.nwords, c_oracle.KIND_BACKOFF, start_units=["\x00"])
+    want_keys = cm.sample(n_cut, seed, first_id=first)["ml2p"]
+    assert np.array_equal(want_keys.view(np.uint64), keys[:n_cut].cpu().numpy().view(np.uint64))
+    osrt, opos = c_oracle.rank_build(want_keys)
+    sc_cut = sc[:t_cut].contiguous()
+    o_order = np.argsort(sc_cut.cpu().numpy(), kind="stable")
+    o_scores = sc_cut.cpu().numpy()[o_order]
+    o_pos, o_cnt = c_oracle.rank_query(osrt, opos, o_scores)[:2]
+    est = np.where(np.asarray(o_cnt) > 0, o_pos, 1.0)
+    want, prev = [], 0
+    for e in est.tolist():
+        prev = int(np.ceil(max(e, prev + 1)))
+        want.append(prev)
+    rk2 = DeviceRank(keys[:n_cut].contiguous(), index=args.rank_index)
+    srt2, order2 = device_order(sc_cut)
+    pos2, cnt2 = rk2.query(srt2)
+    ranks2, exact2, _ = device_guess_numbers(pos2, cnt2, True)
+    torch.cuda.synchronize()
+    assert np.array_equal(order2.cpu().numpy().view(np.uint32), o_order.astype(np.uint32))
+    assert np.array_equal(cnt2.cpu().numpy(), np.asarray(o_cnt, dtype=np.int64))
+    p2 = pos2.cpu().numpy()
+    rel = float(np.max(np.abs(p2 - o_pos) / np.maximum(np.abs(o_pos), 1e-300)))
+    assert rel <= 1e-9, rel
+    k = int(exact2.item())
+    g = ranks2.cpu().numpy()[:k]
+    differ = int(np.sum(g != np.array(want[:k], dtype=np.int64)))
+    assert differ <= 2 and all(abs(int(a) - b) <= 1e-9 * b + 1 for a, b in zip(g.tolist(), want[:k]))
+    res.update({"oracle_cut": f"{n_cut} samples, {t_cut} test passwords", "positions_max_rel_diff_vs_oracle": rel,
+                "guess_numbers_differing_from_oracle": differ, "guess_numbers_compared_with_oracle": k})
+    return res
+
+
+def other_configs(dev):
+    """BASELINE configs 3, 4, 5 and the sub-word scorer once each at their per-GPU sizes, after the timed region:
+    device time of the launches (HIP events; inputs, outputs and workspaces resident, nothing copied or allocated
+    between the events), the bytes the kernels have to move by their own counters, and the fraction of 8 TB/s."""
+    import tempfile
+
+    from montecarlo_amd.bpe_simulator import BpePcfgSim
+    from montecarlo_amd.nwords_simulator_v2 import NWords2MonteCarlo
+    out = {}
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
+
+    def sample_line(dm, n, ms, cnt, reps):
+        draws, ind, probes = cnt["draws"] / reps, cnt["indirect_draws"] / reps, cnt["cdf_probes"] / reps
+        byts = draws * B_DRAW + ind * B_INDIRECT + probes * B_PROBE + n * B_SAMPLE
+        return {"ms": ms, "samples_per_s": n / (ms * 1e-3), "draws_per_sample": draws / n, "bytes": byts,
+                "frac_of_hbm": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+    # ---- config 3: nwords_v2 6-gram, 1e10 samples over 8 GPUs = 1.25e9 a GPU: sample, rank build, 1e6 queries ----
+    free, _ = torch.cuda.mem_get_info()
+    n3 = 1_250_000_000 if free > 70 * 2 ** 30 else 125_000_000
+    m3 = NWords2MonteCarlo(synth.as_file(synth.v2_corpus(100000)), 6)
+    keys = torch.empty(n3, dtype=torch.float64, device=dev)
+    srt, pos = torch.empty_like(keys), torch.empty_like(keys)
+    ws = torch.empty(nv.lib.mc_rank_workspace_bytes(n3), dtype=torch.uint8, device=dev)
+    nv.check(nv.lib.mc_workspace_forget(C_vp(ws), n3, C_stream(dev)))
+    m3._dev.check()
+    ms = timed(lambda: m3._dev.sample(n3, 5, first_id=3 * n3, out=keys), reps=2)
+    c3 = sample_line(m3._dev, n3, ms, m3._dev.check(), 3)
+    ms_rank = timed(lambda: DeviceRank(keys, n_global=8 * n3, workspace=ws, keys_sorted=srt, positions=pos), reps=2)
+    rk = DeviceRank(keys, n_global=8 * n3, workspace=ws, keys_sorted=srt, positions=pos)
+    x = srt[:: max(1, n3 // 1_000_000)][:1_000_000].contiguous()
+    qp, qc = torch.empty_like(x), torch.empty(x.numel(), dtype=torch.int64, device=dev)
+    ms_q = timed(lambda: rk.query(x, out_pos=qp, out_cnt=qc))
+    info = rk.check()
+    assert info["error"] == 0 and bool((qc[1:] >= qc[:-1]).all()) and int(qc[-1]) <= n3
+    out["config3_nwords_v2_6gram"] = {
+        "what": f"{n3} samples (one GPU's share of 1e10 over 8) of the 100k-line synthetic v2 6-gram model: k_sample, "
+                f"mc_rank_build (expanded arrays: beyond the run index's 2^26 keys), {x.numel()} queries",
+        "k_sample": c3,
+        "mc_rank_build": {"ms": ms_rank, "keys_per_s": n3 / (ms_rank * 1e-3), "bytes": n3 * B_RANK,
+                          "frac_of_hbm": n3 * B_RANK / (ms_rank * 1e-3) / 1e9 / HBM_PEAK_GBS, "sort": info},
+        "k_query": {"ms": ms_q, "queries_per_s": x.numel() / (ms_q * 1e-3)},
+        "pipeline_samples_per_s": n3 / ((ms + ms_rank + ms_q) * 1e-3)}
+    del keys, srt, pos, ws, rk, x, qp, qc
+    torch.cuda.empty_cache()
+
+    # ---- config 4: BPE-PCFG, 1e9 samples over 8 GPUs = 1.25e8 a GPU; 1e6 test passwords scored ----
+    n4 = 125_000_000
+    with tempfile.TemporaryDirectory() as tmp:
+        synth.zipf_bpe_dir(tmp, np.random.default_rng(4))
+        m4 = BpePcfgSim(tmp)
+    keys = torch.empty(n4, dtype=torch.float64, device=dev)
+    m4._dev.check()
+    ms = timed(lambda: m4._dev.sample(n4, 3, out=keys), reps=2)
+    c4 = sample_line(m4._dev, n4, ms, m4._dev.check(), 3)
+    res = m4._dev.sample(200_000, 5, want_len=True, sym_stride=m4._flat.max_segments)
+    pw = list(dict.fromkeys(m4._flat.decode_entries(res["syms"].cpu().numpy(), res["len"].cpu().numpy())))
+    pw = (pw * (1_000_000 // len(pw) + 1))[:1_000_000]
+    cps, cls, off = m4.encode(pw)
+    d_cps = torch.from_numpy(np.ascontiguousarray(cps, dtype=np.uint32).view(np.int32)).to(dev)
+    d_cls = torch.from_numpy(np.ascontiguousarray(cls, dtype=np.uint8)).to(dev)
+    d_off = torch.from_numpy(np.ascontiguousarray(off, dtype=np.uint64).view(np.int64)).to(dev)
+    sc = torch.empty(len(pw), dtype=torch.float64, device=dev)
+    m4._dev.check()
+    ms_s = timed(lambda: m4._dev.score_bpe_device(d_cps, d_cls, d_off, len(pw), sc))
+    cs = m4._dev.check()
+    sbytes = cs["score_probes"] / 4 * 16 + cps.nbytes + cls.nbytes + off.nbytes + sc.numel() * 8
+    assert bool(torch.isfinite(sc).all())
+    out["config4_bpe_pcfg"] = {
+        "what": f"{n4} samples (one GPU's share of 1e9 over 8) of a synthetic BPE-PCFG model (400 structures, terminal "
+                f"rows up to 1e5 entries): k_sample_bpe; {len(pw)} test passwords scored: k_score_bpe",
+        "k_sample_bpe": c4,
+        "k_score_bpe": {"ms": ms_s, "passwords_per_s": len(pw) / (ms_s * 1e-3), "bytes": sbytes,
+                        "hash_probes_per_password": cs["score_probes"] / 4 / len(pw),
+                        "frac_of_hbm": sbytes / (ms_s * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+    del keys, d_cps, d_cls, d_off, sc
+    torch.cuda.empty_cache()
+
+    # ---- sub-word backoff model: calc_ml2p's DFS over segmentations on 1e6 resident passwords ----
+    sub = synth.subword_corpus(100000)
+    ms_model = BackWordsMonteCarlo(synth.as_file(sub), splitter="\t", threshold=10)
+    test = ["".join(ln.split("\t")) for ln in synth.subword_corpus(1_000_000, stream=1)]
+    cps, off, max_len = ms_model._flat.encode_text(test)
+    d_cps = torch.from_numpy(np.ascontiguousarray(cps, dtype=np.uint32).view(np.int32)).to(dev)
+    d_off = torch.from_numpy(np.ascontiguousarray(off, dtype=np.uint64).view(np.int64)).to(dev)
+    sc = torch.empty(len(test), dtype=torch.float64, device=dev)
+    wsw = torch.empty(max(1, nv.lib.mc_score_words_workspace_bytes(ms_model._dev._h, len(test), max_len)),
+                      dtype=torch.uint8, device=dev)
+    ms_model._dev.check()
+    ms_w = timed(lambda: ms_model._dev.score_words_device(d_cps, d_off, len(test), max_len, 10 ** 20, sc, wsw))
+    cw = ms_model._dev.check()
+    wbytes = cw["score_probes"] / 4 * 16 + cps.nbytes + off.nbytes + sc.numel() * 8
+    out["subword_backoff_scoring"] = {
+        "what": f"{len(test)} test passwords (max {max_len} characters) through calc_ml2p's DFS over segmentations on "
+                f"the 100k-line tab-split backoff model ({int(ms_model._flat.info[nv.INFO_NENT])} entries): k_score_words",
+        "k_score_words": {"ms": ms_w, "passwords_per_s": len(test) / (ms_w * 1e-3), "bytes": wbytes,
+                          "hash_probes_per_password": cw["score_probes"] / 4 / len(test),
+                          "frac_of_hbm": wbytes / (ms_w * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+    del d_cps, d_off, sc, wsw
+    torch.cuda.empty_cache()
+
+    # ---- config 5: one round of the secondary-training driver at --size 1e7 (a host loop around the calls above) ----
+    import random
+
+    from montecarlo_amd import backwords_secondary_main as bsm
+    with tempfile.TemporaryDirectory() as tmp:
+        with open(os.path.join(tmp, "train.txt"), "w") as f:
+            f.write("\n".join(synth.zipf_corpus(100000)) + "\n")
+        with open(os.path.join(tmp, "test.txt"), "w") as f:
+            f.write("\n".join(synth.zipf_corpus(100000, oov_frac=0.01, stream=1)) + "\n")
+        random.seed(5)
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(sys.stderr):       # (the driver's progress lines: stdout carries the JSON line only)
+            bsm.wrapper(["-i", os.path.join(tmp, "train.txt"), "-t", os.path.join(tmp, "test.txt"), "-s",
+                         os.path.join(tmp, "out"), "--strategy", "samples", "1", "--size", "10000000"])
+        torch.cuda.synchronize()
+        secs = time.perf_counter() - t0
+        cracked = sum(1 for _ in open(os.path.join(tmp, "out", "cracked-iter-0.txt")))
+    out["config5_secondary_round"] = {
+        "what": "backwords_secondary_main --strategy samples 1 --size 10000000 on 100k training and 100k test lines: one "
+                "round (train, 1e7 samples with their strings deduplicated on the GPU, samples file, rank, score, "
+                "cracked set) + the final model's pass, files written; wall clock of the whole driver, host work included",
+        "seconds": secs, "cracked_in_round": cracked}
+    return out
 
 
 def cpu_baseline(model, test, n_samples: int):

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MC_ABI_VERSION 1
+#define MC_ABI_VERSION 2  /* 2: mc_format_gc_cps takes the number of unique lines; the run-length rank index */
 
 typedef enum mc_status {
     MC_OK = 0,
@@ -283,11 +283,12 @@ int64_t mc_lines_array(const mc_lines *l, int what, void *dst, size_t cap);
 int64_t mc_format_gc(const char *pwds_utf8, size_t bytes, uint64_t n, const double *mlp, const int64_t *appearance,
                      const int64_t *rank, const int64_t *cracked, const double *ratio, char *dst, size_t cap);
 
-/* The same lines with the passwords as the code points of mc_lines_ingest (MC_LINES_CPS, MC_LINES_OFF) and an
- * order: row i is unique line order[i] (n rows).  len(cps) * 4 + 120 * n bytes are always enough.  A lone
- * surrogate among the code points has no UTF-8 form: MC_ERR_ARG (the caller writes such a file with the
- * reference's loop). */
-int64_t mc_format_gc_cps(const uint32_t *cps, const uint64_t *off, const uint32_t *order, uint64_t n,
+/* The same lines with the passwords as the code points of mc_lines_ingest (MC_LINES_CPS, MC_LINES_OFF: n_lines unique
+ * lines, off[n_lines + 1]) and an order: row i is unique line order[i] (n rows; an order[i] >= n_lines is MC_ERR_ARG,
+ * nothing is read through it).  len(cps) * 4 + 120 * n bytes are always enough.  A lone surrogate among the code
+ * points has no UTF-8 form: MC_ERR_ARG (the caller writes such a file with the reference's loop).  Runs on as many
+ * threads as it can start (at most 16, at least the caller's own); MC_ERR_NOMEM when memory runs out. */
+int64_t mc_format_gc_cps(const uint32_t *cps, const uint64_t *off, uint64_t n_lines, const uint32_t *order, uint64_t n,
                          const double *mlp, const int64_t *appearance, const int64_t *rank, const int64_t *cracked,
                          const double *ratio, char *dst, size_t cap);
 

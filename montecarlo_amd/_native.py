@@ -97,7 +97,7 @@ def _load() -> C.CDLL:
         "mc_enum_fetch": (C.c_int64, [vp, C.c_int, vp, C.c_size_t]),
         "mc_enum_free": (None, [vp]),
         "mc_format_gc": (C.c_int64, [C.c_char_p, C.c_size_t, C.c_uint64, vp, vp, vp, vp, vp, vp, C.c_size_t]),
-        "mc_format_gc_cps": (C.c_int64, [vp, vp, vp, C.c_uint64, vp, vp, vp, vp, vp, vp, C.c_size_t]),
+        "mc_format_gc_cps": (C.c_int64, [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vp, vp, vp, C.c_size_t]),
         "mc_lines_ingest": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(vp)]),
         "mc_lines_free": (None, [vp]),
         "mc_lines_array": (C.c_int64, [vp, C.c_int, vp, C.c_size_t]),
@@ -145,6 +145,44 @@ def _load() -> C.CDLL:
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = header and library disagree
         fn.restype, fn.argtypes = res, args
+    # MC_HOST_SANITIZED=<libmi355mc_host_san.so> (python -m montecarlo_amd.build --sanitize; the process preloads the
+    # sanitizer's runtime): the entry points that run on the host only -- table compiler, trainers, ingest, writers --
+    # are taken from the library built under AddressSanitizer + UBSan (tests/test_sanitized_host.py)
+    san = os.environ.get("MC_HOST_SANITIZED")
+    if san:
+        host = C.CDLL(san)
+        taken = []
+        failed_in = [lib]                # the library whose entry point failed last: each keeps its own message
+
+        def tracked(fn, owner):
+            def call(*a):
+                rc = fn(*a)
+                if isinstance(rc, int) and rc < 0:
+                    failed_in[0] = owner
+                return rc
+            return call
+
+        main_err = lib.mc_last_error
+        for name, (res, args) in sig.items():
+            if name in ("mc_last_error", "mc_abi_version"):
+                continue
+            if res is not C.c_int:
+                if hasattr(host, name):
+                    fn = getattr(host, name)
+                    fn.restype, fn.argtypes = res, args
+                    setattr(lib, name, fn)
+                    taken.append(name)
+                continue
+            if hasattr(host, name):
+                fn = getattr(host, name)
+                fn.restype, fn.argtypes = res, args
+                setattr(lib, name, tracked(fn, host))
+                taken.append(name)
+            else:
+                setattr(lib, name, tracked(getattr(lib, name), lib))
+        host.mc_last_error.restype, host.mc_last_error.argtypes = C.c_char_p, []
+        lib.mc_last_error = lambda: host.mc_last_error() if failed_in[0] is host else main_err()
+        lib.sanitized_host_entry_points = taken
     return lib
 
 

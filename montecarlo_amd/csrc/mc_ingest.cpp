@@ -145,8 +145,9 @@ extern "C" int mc_lines_ingest(const char *utf8, size_t bytes, mc_lines **out) {
                     }
                     break;
                 }
+                // (n == 0: nothing to compare, and an empty arena's data() may be null -- memcmp must not be handed one)
                 if (s.tag == tag && blen[s.idx - 1] == n &&
-                    std::memcmp(arena.data() + start[s.idx - 1], text + a, n) == 0) {
+                    (n == 0 || std::memcmp(arena.data() + start[s.idx - 1], text + a, n) == 0)) {
                     ++L->count[s.idx - 1];
                     break;
                 }
@@ -185,6 +186,10 @@ extern "C" int mc_lines_ingest(const char *utf8, size_t bytes, mc_lines **out) {
                 ok = (d >> 6) == 2;
                 cp = (cp << 6) | (d & 63);
             }
+            // (overlong forms and values beyond U+10FFFF are not UTF-8 either; surrogates pass: Python's
+            // "surrogatepass" carries undecodable bytes of the file that way)
+            if (ok && ((len == 2 && cp < 0x80u) || (len == 3 && cp < 0x800u) || (len == 4 && (cp < 0x10000u || cp > 0x10FFFFu))))
+                ok = false;
             if (!ok) {
                 delete L;
                 mc_set_error("mc_lines_ingest: the text is not valid UTF-8");
@@ -350,64 +355,88 @@ unsigned usable_threads() {
 
 }  // namespace
 
-extern "C" int64_t mc_format_gc_cps(const uint32_t *cps, const uint64_t *off, const uint32_t *order, uint64_t n,
-                                    const double *mlp, const int64_t *appearance, const int64_t *rank,
+namespace {
+// Runs `work` on up to `threads` threads, the caller's included.  A thread that cannot be started (EAGAIN under a
+// container's thread limit) is simply not there: the others, and in the end the caller alone, take every block.
+template <typename F>
+void run_on_threads(unsigned threads, F &work) {
+    std::vector<std::thread> pool;
+    try {
+        pool.reserve(threads);
+        for (unsigned t = 1; t < threads; ++t) pool.emplace_back([&work]() { work(); });
+    } catch (...) {
+    }
+    work();
+    for (auto &t : pool) t.join();
+}
+}  // namespace
+
+extern "C" int64_t mc_format_gc_cps(const uint32_t *cps, const uint64_t *off, uint64_t n_lines, const uint32_t *order,
+                                    uint64_t n, const double *mlp, const int64_t *appearance, const int64_t *rank,
                                     const int64_t *cracked, const double *ratio, char *dst, size_t cap) {
     if (n && (!cps || !off || !order || !mlp || !appearance || !rank || !cracked || !ratio || !dst)) {
         mc_set_error("mc_format_gc_cps: bad argument");
         return MC_ERR_ARG;
     }
-    const uint64_t blocks = (n + FORMAT_BLOCK - 1) / FORMAT_BLOCK;
-    std::vector<std::unique_ptr<char[]>> buf(blocks);
-    std::vector<int64_t> size(blocks, 0);
-    std::atomic<uint64_t> next{0};
-    std::atomic<int> bad{0};
-    auto work = [&]() {
-        for (uint64_t b = next.fetch_add(1); b < blocks && !bad.load(std::memory_order_relaxed); b = next.fetch_add(1)) {
-            const uint64_t r0 = b * FORMAT_BLOCK, r1 = std::min(n, r0 + FORMAT_BLOCK);
-            uint64_t chars = 0;
-            for (uint64_t i = r0; i < r1; ++i) chars += off[order[i] + 1] - off[order[i]];
-            buf[b].reset(new (std::nothrow) char[4 * chars + 120 * (r1 - r0)]);
-            if (!buf[b]) {
-                bad.store(3);
-                return;
+    try {
+        const uint64_t blocks = (n + FORMAT_BLOCK - 1) / FORMAT_BLOCK;
+        std::vector<std::unique_ptr<char[]>> buf(blocks);
+        std::vector<int64_t> size(blocks, 0);
+        std::atomic<uint64_t> next{0};
+        std::atomic<int> bad{0};
+        auto work = [&]() {
+            for (uint64_t b = next.fetch_add(1); b < blocks && !bad.load(std::memory_order_relaxed); b = next.fetch_add(1)) {
+                const uint64_t r0 = b * FORMAT_BLOCK, r1 = std::min(n, r0 + FORMAT_BLOCK);
+                uint64_t chars = 0;
+                for (uint64_t i = r0; i < r1; ++i) {
+                    // a row names one of the n_lines unique lines, and the lines' offsets ascend: checked before
+                    // anything is read through them
+                    if (order[i] >= n_lines || off[order[i] + 1] < off[order[i]]) {
+                        bad.store(4);
+                        return;
+                    }
+                    chars += off[order[i] + 1] - off[order[i]];
+                }
+                buf[b].reset(new (std::nothrow) char[4 * chars + 120 * (r1 - r0)]);
+                if (!buf[b]) {
+                    bad.store(3);
+                    return;
+                }
+                size[b] = format_rows_cps(cps, off, order, r0, r1, mlp, appearance, rank, cracked, ratio, buf[b].get());
+                if (size[b] < 0) bad.store(size[b] == -1 ? 1 : 2);
             }
-            size[b] = format_rows_cps(cps, off, order, r0, r1, mlp, appearance, rank, cracked, ratio, buf[b].get());
-            if (size[b] < 0) bad.store(size[b] == -1 ? 1 : 2);
+        };
+        const unsigned threads = (unsigned)std::min<uint64_t>(usable_threads(), blocks);
+        run_on_threads(threads, work);
+        if (bad.load()) {
+            const int why = bad.load();
+            mc_set_error(why == 1   ? "mc_format_gc_cps: a lone surrogate has no UTF-8 form"
+                         : why == 2 ? "mc_format_gc_cps: a line's numbers do not fit 120 characters"
+                         : why == 4 ? "mc_format_gc_cps: a row names a line beyond the n_lines unique lines (or the "
+                                      "offsets do not ascend)"
+                                    : "mc_format_gc_cps: out of memory");
+            return why == 3 ? MC_ERR_NOMEM : MC_ERR_ARG;
         }
-    };
-    const unsigned threads = (unsigned)std::min<uint64_t>(usable_threads(), blocks);
-    {
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < threads; ++t) pool.emplace_back(work);
-        work();
-        for (auto &t : pool) t.join();
-    }
-    if (bad.load()) {
-        const int why = bad.load();
-        mc_set_error(why == 1 ? "mc_format_gc_cps: a lone surrogate has no UTF-8 form"
-                              : why == 2 ? "mc_format_gc_cps: a line's numbers do not fit 120 characters"
-                                         : "mc_format_gc_cps: out of memory");
-        return why == 3 ? MC_ERR_NOMEM : MC_ERR_ARG;
-    }
-    std::vector<uint64_t> at(blocks + 1, 0);
-    for (uint64_t b = 0; b < blocks; ++b) at[b + 1] = at[b] + (uint64_t)size[b];
-    if (at[blocks] > cap) {
-        mc_set_error("mc_format_gc_cps: output buffer of %zu bytes is too small", cap);
-        return MC_ERR_WORKSPACE;
-    }
-    next.store(0);
-    auto place = [&]() {
-        for (uint64_t b = next.fetch_add(1); b < blocks; b = next.fetch_add(1)) {
-            std::memcpy(dst + at[b], buf[b].get(), (size_t)size[b]);
-            buf[b].reset();
+        std::vector<uint64_t> at(blocks + 1, 0);
+        for (uint64_t b = 0; b < blocks; ++b) at[b + 1] = at[b] + (uint64_t)size[b];
+        if (at[blocks] > cap) {
+            mc_set_error("mc_format_gc_cps: output buffer of %zu bytes is too small", cap);
+            return MC_ERR_WORKSPACE;
         }
-    };
-    {
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < threads; ++t) pool.emplace_back(place);
-        place();
-        for (auto &t : pool) t.join();
+        next.store(0);
+        auto place = [&]() {
+            for (uint64_t b = next.fetch_add(1); b < blocks; b = next.fetch_add(1)) {
+                std::memcpy(dst + at[b], buf[b].get(), (size_t)size[b]);
+                buf[b].reset();
+            }
+        };
+        run_on_threads(threads, place);
+        return (int64_t)at[blocks];
+    } catch (const std::bad_alloc &) {  // (nothing of C++ may leave an extern "C" function: the caller is ctypes)
+        mc_set_error("mc_format_gc_cps: out of memory");
+        return MC_ERR_NOMEM;
+    } catch (...) {
+        mc_set_error("mc_format_gc_cps: an unexpected C++ exception");
+        return MC_ERR_ARG;
     }
-    return (int64_t)at[blocks];
 }

@@ -16,6 +16,7 @@
 // the columns between occurrences of the one-character splitter, taken first::step.
 #include "mc_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -168,6 +169,8 @@ bool decode_utf8(const char *p, size_t n, Seq &out) {
             if ((d >> 6) != 2) return false;
             cp = (cp << 6) | (d & 63);
         }
+        // (overlong forms and values beyond U+10FFFF are not UTF-8 either; surrogates pass, as Python's "surrogatepass")
+        if ((len == 2 && cp < 0x80u) || (len == 3 && cp < 0x800u) || (len == 4 && (cp < 0x10000u || cp > 0x10FFFFu))) return false;
         out.push_back(cp);
         i += len;
     }

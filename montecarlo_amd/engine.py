@@ -152,6 +152,24 @@ class DeviceModel:
         return res, split
 
 
+    def score_words_device(self, d_cps: torch.Tensor, d_off: torch.Tensor, count: int, max_len: int, iter_max: int,
+                           out: torch.Tensor, workspace: torch.Tensor, split: torch.Tensor = None):
+        """mc_score_words on inputs, output and workspace (mc_score_words_workspace_bytes) that already live on the
+        GPU: nothing is copied, allocated or waited for."""
+        with torch.cuda.device(self.tdev):
+            nv.check(nv.lib.mc_score_words(self._h, _vp(d_cps), _vp(d_off), count, max_len,
+                                           min(int(iter_max), 0xFFFFFFFFFFFFFFFF) if iter_max > 0 else 0, _vp(out),
+                                           _vp(split), split.shape[1] if split is not None else 0, _vp(workspace),
+                                           workspace.numel(), self._stream()))
+        return out
+
+    def score_bpe_device(self, d_cps: torch.Tensor, d_cls: torch.Tensor, d_off: torch.Tensor, count: int,
+                         out: torch.Tensor):
+        """mc_score_bpe on resident inputs and output."""
+        with torch.cuda.device(self.tdev):
+            nv.check(nv.lib.mc_score_bpe(self._h, _vp(d_cps), _vp(d_cls), _vp(d_off), count, _vp(out), self._stream()))
+        return out
+
     def score_bpe(self, cps: np.ndarray, cls: np.ndarray, off: np.ndarray) -> torch.Tensor:
         count = len(off) - 1
         with torch.cuda.device(self.tdev):

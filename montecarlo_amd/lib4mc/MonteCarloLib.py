@@ -206,7 +206,7 @@ def _format_native(gc) -> "str | None":
         lines = gc.scored.lines
         order = numpy.ascontiguousarray(gc.scored.order, dtype=numpy.uint32)
         out = numpy.empty(4 * len(lines.cps) + 120 * n, dtype=numpy.uint8)       # (not zero-filled)
-        size = nv.lib.mc_format_gc_cps(vp(lines.cps), vp(lines.off), vp(order), n, vp(mlp), vp(apps), vp(rank),
+        size = nv.lib.mc_format_gc_cps(vp(lines.cps), vp(lines.off), len(lines.off) - 1, vp(order), n, vp(mlp), vp(apps), vp(rank),
                                        vp(crk), vp(ratio), vp(out), out.size)
         if size >= 0:
             return str(memoryview(out)[:size], "utf-8")

@@ -7,7 +7,7 @@ coalesced reads -> doubled here (`fetch_bytes_corrected`); WRITE_SIZE is exact. 
 gathers are uncalibrated by the guide, so both raw and corrected figures are kept.
 
 The sort's kernels run three times a step (mc_rank_build, and twice inside mc_order_keys): the per-stage totals
-follow the dispatches in order (k_sample opens a step, k_positions closes the rank build, k_order_prep .. k_order_out
+follow the dispatches in order (k_sample opens a step, k_positions or k_rl_final closes the rank build, k_order_prep .. k_order_out
 bracket the order; since r02-m, which dropped k_order_prep, the order starts with the first kernel after k_score).  `_per_step` also carries the digest of the native sources the numbers were measured on.
 """
 import csv
@@ -71,8 +71,7 @@ def per_stage(rs):
         if stage is None or base.startswith("at::") or "rocclr_copy" in base:
             continue
         tot[stage] += v
-        if base == "k_positions":
-            stage = "after_rank_build"
+XX
         elif base == "k_order_out":
             stage = "after_order"
     return tot, steps

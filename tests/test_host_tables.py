@@ -39,7 +39,7 @@ def test_library_exports_header_symbols():
     lib = ctypes.CDLL(nv.LIB_PATH)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert nv.lib.mc_abi_version() == 1
+    assert nv.lib.mc_abi_version() == 2
 
 
 def check_table(fx, model):
@@ -457,17 +457,17 @@ def test_format_gc_cps_equals_fstrings():
     ratio = crk / float(crk[-1]) * 100
     vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
     out = np.empty(4 * len(lines.cps) + 120 * n, dtype=np.uint8)
-    size = nv.lib.mc_format_gc_cps(vp(lines.cps), vp(lines.off), vp(order), n, vp(mlp), vp(apps), vp(rank), vp(crk),
+    size = nv.lib.mc_format_gc_cps(vp(lines.cps), vp(lines.off), len(lines.off) - 1, vp(order), n, vp(mlp), vp(apps), vp(rank), vp(crk),
                                    vp(ratio), vp(out), out.size)
     want = "".join(f"{pw[o]}\t{m:.8f}\t{a}\t{r}\t{c}\t{q:5.2f}\n"
                    for o, m, a, r, c, q in zip(order.tolist(), mlp.tolist(), apps.tolist(), rank.tolist(),
                                                crk.tolist(), ratio.tolist()))
     assert size == len(want.encode("utf-8")) and bytes(out[:size]).decode("utf-8") == want
-    assert nv.lib.mc_format_gc_cps(vp(lines.cps), vp(lines.off), vp(order), n, vp(mlp), vp(apps), vp(rank), vp(crk),
+    assert nv.lib.mc_format_gc_cps(vp(lines.cps), vp(lines.off), len(lines.off) - 1, vp(order), n, vp(mlp), vp(apps), vp(rank), vp(crk),
                                    vp(ratio), vp(out), 100) < 0                     # dst too small
     bad = UniqueLines("ab\n\ud800x\n")
     two = np.arange(2, dtype=np.uint32)
-    assert nv.lib.mc_format_gc_cps(vp(bad.cps), vp(bad.off), vp(two), 2, vp(mlp), vp(apps), vp(rank), vp(crk),
+    assert nv.lib.mc_format_gc_cps(vp(bad.cps), vp(bad.off), len(bad.off) - 1, vp(two), 2, vp(mlp), vp(apps), vp(rank), vp(crk),
                                    vp(ratio), vp(out), out.size) < 0
 
 

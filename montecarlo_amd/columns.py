@@ -6,6 +6,10 @@ the list on (``ml2p_iter2gc(parse_file(...))`` then ``write2``: backwords_simula
 them.  These classes behave as the lists they replace -- length, indexing, slicing, iteration, comparison with a
 list, item assignment -- and build the tuples when somebody looks; until a caller CHANGES one, ``pristine`` says
 the columns still are the truth and the next stage (``ml2p_iter2gc``, ``write2``) reads them directly.
+
+Where they are NOT a ``list``: ``isinstance(x, list)`` is False, so ``json.dumps(x)`` refuses them (pass
+``list(x)``, or ``default=list``); ``list + x`` and ``x + list`` both give a plain list of the rows; pickling and
+``copy.copy`` give a plain list of the rows too (the columns reference GPU-side objects that do not travel).
 """
 from __future__ import annotations
 
@@ -68,6 +72,12 @@ class _ColumnList(collections.abc.MutableSequence):
 
     def __add__(self, other):
         return self._materialise() + list(other)
+
+    def __radd__(self, other):
+        return list(other) + self._materialise()
+
+    def __reduce__(self):                 # pickle / copy: the rows as a plain list
+        return (list, (self._materialise(),))
 
     def __repr__(self):
         return repr(self._materialise())

@@ -55,7 +55,10 @@ void bind_rccl() {
 
 bool have_rccl(const char *who) {
     std::call_once(g_once, bind_rccl);
-    if (!g_ok) mc_set_error("%s: RCCL (librccl.so) could not be loaded: %s", who, dlerror() ? dlerror() : "symbols missing");
+    if (!g_ok) {
+        const char *why = dlerror();      // (one call: reading the message clears it)
+        mc_set_error("%s: RCCL (librccl.so) could not be loaded: %s", who, why ? why : "symbols missing");
+    }
     return g_ok;
 }
 

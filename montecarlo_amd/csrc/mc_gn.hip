@@ -376,8 +376,15 @@ __global__ void __launch_bounds__(GN_THREADS) k_gn_ranks(const double *__restric
 
 }  // namespace
 
+// digit tables of the LSD passes (t <= LS_MAX_T): 256 counters a tile + 256 totals, in a region of their own behind
+// the failure word -- the head of the sort's workspace holds its control block and the hint a later sort reuses
+static size_t lsd_table_bytes(uint64_t t) {
+    if (t > LS_MAX_T) return 0;
+    return align256(((size_t)256 * ((t + LS_TILE - 1) / LS_TILE) + 256) * sizeof(u32));
+}
+
 extern "C" size_t mc_order_workspace_bytes(uint64_t t) {
-    return align256(mc_sort_workspace_bytes(t)) + 2 * align256(t * sizeof(u64)) + 256;
+    return align256(mc_sort_workspace_bytes(t)) + 2 * align256(t * sizeof(u64)) + 256 + lsd_table_bytes(t);
 }
 
 extern "C" int mc_order_keys(const double *x, uint64_t t, double *x_sorted, uint32_t *order, void *workspace,
@@ -409,10 +416,10 @@ extern "C" int mc_order_keys(const double *x, uint64_t t, double *x_sorted, uint
     const u32 gw = (u32)((t + 2047) / 2048 < 512 ? (t + 2047) / 2048 : 512);
     if (t <= LS_MAX_T) {
         // (L, index) pairs through stable LSD passes; the buffers of the words hold two u32 arrays each, the
-        // digit tables take the head of the sort's workspace (the sort is over by then, its error word read)
+        // digit tables have a region of their own (lsd_table_bytes)
         u32 *ka = (u32 *)words, *pa = ka + t, *kb = (u32 *)words_sorted, *pb = kb + t;
         const u32 tiles = (u32)((t + LS_TILE - 1) / LS_TILE);
-        u32 *table = (u32 *)workspace, *totals = table + (size_t)256 * tiles;
+        u32 *table = (u32 *)((char *)failed + 256), *totals = table + (size_t)256 * tiles;
         hipLaunchKernelGGL(k_order_words<false>, dim3(gw), dim3(OW_THREADS), 0, s, (const u64 *)x_sorted, (const u64 *)x,
                            (u64)t, stride, words, (const u32 *)err1, failed);
         int nbits = 1;

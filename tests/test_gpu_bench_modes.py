@@ -36,7 +36,7 @@ def test_bench_step_arrangements(extra):
     if "sorted" in extra:
         assert chk["guess_numbers_differing_from_serial_recompute"] == 0
     assert chk["positions_max_rel_diff_vs_oracle"] <= 1e-9 and chk["guess_numbers_differing_from_oracle"] <= 2
-    assert line["first_step_ms"] > 0 and line["cold_step_ms"] > 0
+    assert line["cold_step_ms"] > 0 and ("--warmup" in extra or line["first_step_ms"] > 0)
     assert (line["stage_ms"]["d2h"] is None) == ("--d2h" not in extra)
 
 

@@ -490,6 +490,18 @@ def test_column_lists_behave_as_the_lists_they_replace():
     gcl = GcList(sc, ranks, crk, crk / float(crk[-1]) * 100)
     rows = [(p, m, a, r, c, c / int(crk[-1]) * 100) for (p, a, m), r, c in zip(want, ranks.tolist(), crk.tolist())]
     assert gcl == rows and gcl.pristine and len(gcl) == 50
+    # concatenation from either side, pickling, copying and JSON: plain lists of the rows (columns.py, module text)
+    import copy
+    import json
+    import pickle
+    head = [("x", 1, 0.5)]
+    assert head + sc == head + want and sc + head == want + head and type(head + sc) is list
+    assert pickle.loads(pickle.dumps(gcl)) == rows and type(pickle.loads(pickle.dumps(sc))) is list
+    assert copy.copy(sc) == want and copy.deepcopy(gcl) == rows
+    with pytest.raises(TypeError):
+        json.dumps(sc)
+    assert json.loads(json.dumps(sc, default=list)) == [list(r) for r in want]
+    assert json.loads(json.dumps(list(gcl))) == [list(r) for r in rows]
     gcl[0] = ("zz", 1.0, 1, 1, 1, 1.0)
     assert not gcl.pristine and gcl[0][0] == "zz" and gcl[1:] == rows[1:]
     sc.sort(key=lambda r: r[0])

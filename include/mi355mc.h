@@ -382,6 +382,13 @@ size_t mc_score_words_workspace_bytes(const mc_model *m, uint64_t count, uint32_
 int mc_score_words(mc_model *m, const uint32_t *cps, const uint64_t *off, uint64_t count, uint32_t max_len,
                    uint64_t iter_max, double *out_ml2p, uint64_t *out_split, uint32_t split_words,
                    void *workspace, size_t workspace_bytes, void *stream);
+/* Test / measurement hook: which kernel mc_score_words launches.  0 (default): by size -- passwords of at most 32
+ * characters with the end symbol's, on a model whose symbols are at most 32 characters, go through
+ * k_score_words_fast (characters in LDS, every length of a position looked up in one round of loads from the
+ * two-choice symbol table, frames stored only where candidates are left behind), all others through k_score_words
+ * (one probe after another, frames in memory).  1: k_score_words always.  Both give the same values, splits and
+ * counters (tests/test_gpu_config_shapes.py).  Environment MC_SCORE_WORDS_KERNEL=dfs does the same for a process. */
+void mc_score_words_debug_kernel(int which);
 
 /* ---- BPE-PCFG scoring: BpePcfgSim.calc_ml2p over a batch (bpe_simulator.py:118-150).  cls[] holds
  * luds' character class of every code point (0..3 = L U D S), decided on the host with Python's own

@@ -14,7 +14,8 @@ import os
 import torch  # noqa: F401  (device memory, streams and torch.distributed are torch's anyway)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355mc.so")
+# (MC_LIB_PATH: another build of the same sources, for A/B timing of a compile-time choice; development only)
+LIB_PATH = os.environ.get("MC_LIB_PATH") or os.path.join(_HERE, "libmi355mc.so")
 
 MC_NONE = 0xFFFFFFFF
 KIND_NGRAM, KIND_BACKOFF, KIND_V2, KIND_BPE = 1, 2, 3, 4
@@ -141,6 +142,7 @@ def _load() -> C.CDLL:
         "mc_rank_runs_query": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp]),
         "mc_rank_runs_expand": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.c_uint64, vp, vp, vp]),
         "mc_rank_runs_debug_phases": (C.c_int, [C.c_int, u64p]),
+        "mc_score_words_debug_kernel": (None, [C.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = header and library disagree
@@ -192,7 +194,8 @@ EXPORTS = ["mc_abi_version", "mc_last_error", "mc_table_compile", "mc_table_free
            "mc_counts_merge", "mc_counts_train", "mc_counts_import", "mc_counts_array", "mc_trained_array", "mc_trained_compile", "mc_lines_ingest", "mc_lines_free", "mc_lines_array", "mc_format_gc", "mc_format_gc_cps", "mc_model_upload", "mc_model_destroy", "mc_model_check", "mc_sample", "mc_sample_carry", "mc_sample_tune", "mc_sample_injected", "mc_sample_dedup",
            "mc_score", "mc_rank_workspace_bytes", "mc_rank_build", "mc_rank_check", "mc_rank_debug_fail", "mc_rank_debug_search", "mc_workspace_forget", "mc_rank_noalloc_max_keys", "mc_rank_build_noalloc", "mc_rank_query", "mc_order_workspace_bytes", "mc_order_keys", "mc_guess_numbers_workspace_bytes", "mc_guess_numbers", "mc_comm_unique_id", "mc_comm_init", "mc_allreduce_rank", "mc_comm_destroy", "mc_enumerate", "mc_enum_info", "mc_enum_fetch",
            "mc_enum_free", "mc_rank_runs_workspace_bytes", "mc_rank_runs_capacity", "mc_rank_runs_max_keys", "mc_rank_runs_build",
-           "mc_rank_runs_forget", "mc_rank_runs_check", "mc_rank_runs_query", "mc_rank_runs_expand", "mc_rank_runs_debug_phases"]
+           "mc_rank_runs_forget", "mc_rank_runs_check", "mc_rank_runs_query", "mc_rank_runs_expand", "mc_rank_runs_debug_phases",
+           "mc_score_words_debug_kernel"]
 
 
 def check(rc: int) -> int:

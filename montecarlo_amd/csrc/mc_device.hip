@@ -14,6 +14,7 @@
 // looking transitions up in the (row,symbol) hash and following parent links to back off.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -58,13 +59,14 @@ struct DevModel {
     const Slot *ctxhash;
     const uint32_t *sym_chars;
     const Slot *wordhash;
+    const unsigned long long *wordck;  // the two-choice table of the same map (mc_internal.h), or null
     const uint32_t *sym_text_off, *sym_text;
     const Payload *dense;
     unsigned long long *status;
     unsigned long long trans_mask, ctx_mask;
     uint32_t start_state, root, end_sym, min_len, max_len, flags, n_ctx, n_sym;
     uint32_t start_draw, start_gbits;
-    unsigned long long word_mask;
+    unsigned long long word_mask, wordck_mask;
     uint32_t max_word_len, start_sym, end_text_off, end_text_len;
     // MC_KIND_BPE
     const uint32_t *seg_off, *seg_row, *seg_len;
@@ -510,6 +512,25 @@ __device__ __forceinline__ uint32_t find_entry(const DevModel &m, uint32_t state
     return MC_NONE;
 }
 
+// find_entry with the row's parent requested beside the row's first probe (one round trip a backoff level, not two)
+__device__ __forceinline__ uint32_t find_entry_ahead(const DevModel &m, uint32_t state, uint32_t s, unsigned int &c_probe) {
+    uint32_t row = state;
+    while (row != MC_NONE) {
+        const unsigned long long key = ((unsigned long long)row << 32) | s;
+        unsigned long long q = mix64(key + 0x9E3779B97F4A7C15ull) & m.trans_mask;
+        const uint32_t parent = m.state[row].parent;
+        for (;;) {
+            const Slot sl = m.trans[q];
+            ++c_probe;
+            if (sl.key == key) return sl.val;
+            if (sl.key == ~0ull) break;
+            q = (q + 1) & m.trans_mask;
+        }
+        row = parent;
+    }
+    return MC_NONE;
+}
+
 // DENSE: the model has the resolved (row, symbol) table, a step is one 16-byte gather; otherwise
 // the (row,symbol) hash is probed along the backoff chain.  A lane walks NP passwords at a time
 // (independent chains: the kernel is bound by gather latency, not by issue).
@@ -712,6 +733,231 @@ __global__ void __launch_bounds__(256) k_score_words(DevModel m, WordsArgs a) {
             if (!advanced) --depth;
         }
         a.out[t] = best;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        c_probe += __shfl_down(c_probe, o);
+        c_step += __shfl_down(c_step, o);
+        c_long += __shfl_down(c_long, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&status_slot(m)[MC_CNT_SCORE_PROBES], (unsigned long long)c_probe);
+        atomicAdd(&status_slot(m)[MC_CNT_SCORE_STEPS], (unsigned long long)c_step);
+        if (c_long) atomicAdd(&status_slot(m)[MC_CNT_SCORE_TOO_LONG], (unsigned long long)c_long);
+    }
+}
+
+// ---- the same DFS for short passwords: at most WF_MAX characters with the end symbol's, symbols of at most WF_MAX.
+// k_score_words above is a chain of some 600 dependent loads a password (characters, one probe after another, the
+// stack in memory); here a lane keeps its password's characters in LDS, looks up ALL lengths of a position at once
+// (independent gathers), keeps the frame it works on in registers, stores a frame only when it leaves candidates
+// behind (a position with one candidate -- the common case -- is a tail call) and checks a candidate's text beside
+// its transition look-up.  Same order of the search, same running sums, same counters of parses: same results.
+//   LDS: character j of the lane's password at s_ch[j * 256], symbol of the candidate of length k + 1 at s_sym[k * 256]
+//   a stored frame: sum so far, automaton state, lengths not tried yet, split ends of the path (its highest bit = pos - 1)
+constexpr uint32_t WF_MAX = 32;
+#ifndef WF_WAVES
+#define WF_WAVES 4
+#endif
+struct alignas(8) WFrame {
+    double acc;
+    uint32_t state, rem, path, pad;
+};
+static_assert(sizeof(WFrame) == 24, "frame layout");
+
+constexpr unsigned long long FNV_BASIS = 0xCBF29CE484222325ull, FNV_PRIME = 0x100000001B3ull;
+
+// text[pos : pos + idx] in the symbol table, probe by probe with its text compared (a hit of the batched look-up whose
+// text differs: two texts of one length with one 64-bit hash)
+__device__ __forceinline__ uint32_t words_lookup_exact(const DevModel &m, const uint32_t *s_ch, uint32_t pos, uint32_t idx) {
+    unsigned long long h = FNV_BASIS;
+    for (uint32_t j = 0; j < idx; ++j) h = (h ^ s_ch[(pos + j) * 256u]) * FNV_PRIME;
+    const unsigned long long key = h == ~0ull ? ~0ull - 1 : h;
+    for (unsigned long long q = key & m.word_mask;; q = (q + 1) & m.word_mask) {
+        const Slot sl = m.wordhash[q];
+        if (sl.key == ~0ull) return MC_NONE;
+        if (sl.key == key && sl.pad == idx) {
+            const uint32_t *txt = m.sym_text + m.sym_text_off[sl.val];
+            bool same = true;
+            for (uint32_t j = 0; j < idx; ++j) same = same && txt[j] == s_ch[(pos + j) * 256u];
+            if (same) return sl.val;
+        }
+    }
+}
+
+template <uint32_t CH>  // lengths looked up together: the model's longest symbol when that is below 8
+__global__ void __launch_bounds__(256, WF_WAVES) k_score_words_fast(DevModel m, WordsArgs a, uint32_t rows) {
+    extern __shared__ uint32_t wf_lds[];
+    const uint32_t tid = threadIdx.x;
+    uint32_t *const s_ch = wf_lds + tid;
+    uint32_t *const s_sym = wf_lds + rows * 256u + tid;
+    const uint32_t lane = blockIdx.x * 256u + tid;
+    WFrame *const st = (WFrame *)a.stack + lane;  // stored frame number L at st[L * n_lanes]
+    const size_t fs = a.n_lanes;
+    const uint32_t W = m.max_word_len;
+    unsigned int c_probe = 0, c_step = 0, c_long = 0;
+
+    unsigned long long t_next = lane, t = 0, done = 0;
+    // (the offsets of a lane's next password are fetched while it works on the one before)
+    unsigned long long p0_next = 0, p1_next = 0;
+    if (t_next < a.count) {
+        p0_next = a.off[t_next];
+        p1_next = a.off[t_next + 1];
+    }
+    bool have = false, fresh = false;
+    uint32_t total = 0, depth = 0, best_path = 0, state = 0, pos = 0, path = 0, mask = 0, filter = 0;
+    double best = 0.0, acc = 0.0;
+    for (;;) {
+        if (!have) {  // the next password of this lane
+            if (t_next >= a.count) break;
+            t = t_next;
+            t_next += a.n_lanes;
+            const unsigned long long p0 = p0_next;
+            const uint32_t len = (uint32_t)(p1_next - p0);
+            if (t_next < a.count) {
+                p0_next = a.off[t_next];
+                p1_next = a.off[t_next + 1];
+            }
+            if (a.out_split)
+                for (uint32_t w = 0; w < a.split_words; ++w) a.out_split[t * a.split_words + w] = 0;
+            if (len > a.max_len) {
+                a.out[t] = __longlong_as_double(0x7FF8000000000000ll);
+                ++c_long;
+                continue;
+            }
+            total = len + m.end_text_len;  // len(pwd) + len(end_chr)
+            for (uint32_t j0 = 0; j0 < total; j0 += 8) {
+                uint32_t c[8];
+#pragma unroll
+                for (uint32_t u = 0; u < 8; ++u) {
+                    const uint32_t j = j0 + u;
+                    c[u] = j < len ? a.cps[p0 + j] : (j < total ? m.sym_text[m.end_text_off + (j - len)] : 0u);
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 8; ++u)
+                    if (j0 + u < total) s_ch[(j0 + u) * 256u] = c[u];
+            }
+            best = 1022.0;
+            best_path = 0;
+            done = 0;
+            depth = 0;
+            acc = 0.0;
+            state = m.start_state;
+            pos = 0;
+            path = 0;
+            filter = ~0u;
+            mask = 0;
+            have = fresh = true;
+            if (a.iter_max == 0) {  // the entry check of the outermost call (:39)
+                a.out[t] = best;
+                have = false;
+                continue;
+            }
+        }
+        if (fresh) {
+            // every length of a symbol that can start at pos, looked up together: FNV-1a runs over the characters,
+            // both slots of every length in the two-choice table are independent gathers -- one round trip
+            const uint32_t rest = total - pos, top = rest < W ? rest : W;
+            unsigned long long h = FNV_BASIS;
+            uint32_t found = 0;
+            for (uint32_t base = 0; base < top; base += CH) {
+                unsigned long long key[CH];
+                uint32_t need = 0;
+#pragma unroll
+                for (uint32_t u = 0; u < CH; ++u) {
+                    key[u] = 0;
+                    if (base + u < top) {
+                        h = (h ^ s_ch[(pos + base + u) * 256u]) * FNV_PRIME;
+                        key[u] = h == ~0ull ? ~0ull - 1 : h;
+                        need |= ((filter >> (base + u)) & 1u) << u;
+                    }
+                }
+                unsigned long long s1[CH], s2[CH];
+#pragma unroll
+                for (uint32_t u = 0; u < CH; ++u)
+                    if ((need >> u) & 1u) {
+                        s1[u] = m.wordck[MC_CK_POS1(key[u]) & m.wordck_mask];
+                        s2[u] = m.wordck[MC_CK_POS2(key[u]) & m.wordck_mask];
+                    }
+#pragma unroll
+                for (uint32_t u = 0; u < CH; ++u)
+                    if ((need >> u) & 1u) {
+                        const uint32_t tag = MC_CK_TAG(key[u], base + u + 1u);
+                        const bool in1 = (uint32_t)(s1[u] >> 32) == tag && (uint32_t)s1[u] != MC_NONE;
+                        const bool in2 = (uint32_t)(s2[u] >> 32) == tag && (uint32_t)s2[u] != MC_NONE;
+                        if (in1 || in2) {
+                            found |= 1u << (base + u);
+                            s_sym[(base + u) * 256u] = (uint32_t)(in1 ? s1[u] : s2[u]);
+                        }
+                    }
+            }
+            mask = found & filter;
+            fresh = false;
+        }
+        if (mask == 0) {  // this position is done: back to the last frame that left candidates behind
+            if (depth == 0) {
+                a.out[t] = best;
+                if (a.out_split) a.out_split[t * a.split_words] = best_path;
+                have = false;
+                continue;
+            }
+            --depth;
+            const WFrame f = st[depth * fs];
+            acc = f.acc;
+            state = f.state;
+            filter = f.rem;
+            path = f.path;
+            pos = path ? 32u - (uint32_t)__clz(path) : 0u;
+            fresh = true;  // (its candidates' symbols are looked up again: one round of gathers)
+            continue;
+        }
+        const uint32_t k = (uint32_t)__ffs(mask) - 1u, idx = k + 1u;
+        mask &= mask - 1u;
+        uint32_t sym = s_sym[k * 256u];
+        // `left in self.words`: the table's hit is by hash and length; its text is compared beside the transition
+        // look-up, which a hit by another text (never seen) would repeat
+        const uint32_t toff = m.sym_text_off[sym];
+        uint32_t e = find_entry_ahead(m, state, sym, c_probe);
+        Payload p = m.payload[e == MC_NONE ? 0u : e];
+        uint32_t diff = 0;
+        for (uint32_t j0 = 0; j0 < idx; j0 += 8) {
+            uint32_t tx[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) tx[u] = j0 + u < idx ? m.sym_text[toff + j0 + u] : 0u;
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u)
+                if (j0 + u < idx) diff |= tx[u] ^ s_ch[(pos + j0 + u) * 256u];
+        }
+        if (diff) {
+            sym = words_lookup_exact(m, s_ch, pos, idx);
+            if (sym == MC_NONE) continue;
+            e = find_entry_ahead(m, state, sym, c_probe);
+            p = m.payload[e == MC_NONE ? 0u : e];
+        }
+        // a start symbol is dropped from the components (:50), so a parse through it never reaches target_len
+        if (sym == m.start_sym || e == MC_NONE) continue;
+        const double nacc = acc + p.ml2p;
+        ++c_step;
+        const uint32_t end = pos + idx;
+        if (end == total) {  // a full parse (:51-56); the call it would enter has nothing left to split
+            if (best > nacc) {
+                best = nacc;
+                best_path = path | (1u << (end - 1u));
+            }
+            ++done;
+            continue;
+        }
+        if (done < a.iter_max) {  // the callee's entry check (:39)
+            if (mask) {
+                st[depth * fs] = WFrame{acc, state, mask, path, 0u};
+                ++depth;
+            }
+            acc = nacc;
+            state = p.next;
+            pos = end;
+            path |= 1u << (end - 1u);
+            filter = ~0u;
+            fresh = true;
+        }
     }
     for (int o = 32; o > 0; o >>= 1) {
         c_probe += __shfl_down(c_probe, o);
@@ -1063,6 +1309,8 @@ extern "C" int mc_model_upload(const mc_table *t, int device, mc_model **out) {
     d.sym_text_off = (const uint32_t *)put(t->sym_text_off.data(), t->sym_text_off.size() * sizeof(uint32_t));
     d.sym_text = (const uint32_t *)put(t->sym_text.data(), t->sym_text.size() * sizeof(uint32_t));
     d.word_mask = t->wordhash.empty() ? 0 : t->wordhash.size() - 1;
+    d.wordck = t->wordck.empty() ? nullptr : (const unsigned long long *)put(t->wordck.data(), t->wordck.size() * sizeof(uint64_t));
+    d.wordck_mask = t->wordck.empty() ? 0 : t->wordck.size() - 1;
     d.max_word_len = t->max_word_len;
     d.start_sym = t->start_sym;
     d.end_text_off = t->sym_text_off.empty() ? 0 : t->sym_text_off[t->end_sym];
@@ -1329,10 +1577,40 @@ static uint32_t words_lanes(const mc_model *m, uint64_t count) {
     return (uint32_t)(want < cap ? want : cap);
 }
 
+// k_score_words_fast takes passwords of at most WF_MAX characters (the end symbol's included) on a model whose symbols
+// are at most WF_MAX long (MC_SCORE_WORDS_KERNEL=dfs: never); its workgroups per CU follow from its LDS
+static std::atomic<int> g_words_kernel{0};
+extern "C" void mc_score_words_debug_kernel(int which) { g_words_kernel.store(which); }
+
+static bool words_fast_fits(const mc_model *m, uint32_t max_len) {
+    static const bool never = getenv("MC_SCORE_WORDS_KERNEL") && !strcmp(getenv("MC_SCORE_WORDS_KERNEL"), "dfs");
+    return !never && g_words_kernel.load() != 1 && m->dev.wordck && m->dev.max_word_len >= 1 && m->dev.max_word_len <= WF_MAX && (uint64_t)max_len + m->dev.end_text_len <= WF_MAX;
+}
+
+static size_t words_fast_lds(const mc_model *m, uint32_t max_len) {
+    return ((size_t)max_len + m->dev.end_text_len + m->dev.max_word_len) * 256 * sizeof(uint32_t);
+}
+
+static uint32_t words_fast_lanes(const mc_model *m, uint64_t count, uint32_t max_len) {
+    int per_cu = 0;
+    const uint32_t w = m->dev.max_word_len;
+    const void *fn = w <= 2 ? (const void *)k_score_words_fast<2> : w <= 4 ? (const void *)k_score_words_fast<4>
+                   : w <= 6 ? (const void *)k_score_words_fast<6> : (const void *)k_score_words_fast<8>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, words_fast_lds(m, max_len)) != hipSuccess || per_cu < 1)
+        per_cu = 1;
+    unsigned long long want = ((count + 255) / 256) * 256, cap = (unsigned long long)m->n_cu * (unsigned)per_cu * 256;
+    return (uint32_t)(want < cap ? want : cap);
+}
+
 extern "C" size_t mc_score_words_workspace_bytes(const mc_model *m, uint64_t count, uint32_t max_len) {
     if (!m || count == 0) return 0;
     // deepest recursion: every symbol one character, plus the end symbol, plus the outermost call
-    return (size_t)words_lanes(m, count) * ((size_t)max_len + m->dev.end_text_len + 1) * sizeof(Frame);
+    size_t need = (size_t)words_lanes(m, count) * ((size_t)max_len + m->dev.end_text_len + 1) * sizeof(Frame);
+    if (words_fast_fits(m, max_len)) {
+        const size_t fast = (size_t)words_fast_lanes(m, count, max_len) * ((size_t)max_len + m->dev.end_text_len) * sizeof(WFrame);
+        if (fast > need) need = fast;
+    }
+    return need;
 }
 
 extern "C" int mc_score_words(mc_model *m, const uint32_t *cps, const uint64_t *off, uint64_t count, uint32_t max_len,
@@ -1351,6 +1629,28 @@ extern "C" int mc_score_words(mc_model *m, const uint32_t *cps, const uint64_t *
     if (m->dev.end_text_len == 0 || max_len > 65000u) {
         mc_set_error("mc_score_words: empty end symbol or max_len above 65000");
         return MC_ERR_ARG;
+    }
+    if (words_fast_fits(m, max_len)) {
+        const uint32_t rows = max_len + m->dev.end_text_len;
+        const size_t per_lane = (size_t)rows * sizeof(WFrame);
+        uint32_t lanes = words_fast_lanes(m, count, max_len);
+        if ((size_t)lanes * per_lane > workspace_bytes) lanes = (uint32_t)((workspace_bytes / per_lane) / 256 * 256);
+        if (lanes == 0) {
+            mc_set_error("mc_score_words: workspace of %zu bytes cannot hold 256 DFS stacks of %zu bytes", workspace_bytes,
+                         per_lane);
+            return MC_ERR_WORKSPACE;
+        }
+        WordsArgs a{cps, (const unsigned long long *)off, count, iter_max, out_ml2p, (unsigned long long *)out_split,
+                    (Frame *)workspace, split_words, max_len, lanes};
+        const uint32_t w = m->dev.max_word_len;
+        const dim3 g(lanes / 256), b(256);
+        const size_t lds = words_fast_lds(m, max_len);
+        if (w <= 2) hipLaunchKernelGGL(k_score_words_fast<2>, g, b, lds, (hipStream_t)stream, m->dev, a, rows);
+        else if (w <= 4) hipLaunchKernelGGL(k_score_words_fast<4>, g, b, lds, (hipStream_t)stream, m->dev, a, rows);
+        else if (w <= 6) hipLaunchKernelGGL(k_score_words_fast<6>, g, b, lds, (hipStream_t)stream, m->dev, a, rows);
+        else hipLaunchKernelGGL(k_score_words_fast<8>, g, b, lds, (hipStream_t)stream, m->dev, a, rows);
+        HIP_TRY(hipGetLastError());
+        return MC_OK;
     }
     const size_t per_lane = ((size_t)max_len + m->dev.end_text_len + 1) * sizeof(Frame);
     uint32_t lanes = words_lanes(m, count);

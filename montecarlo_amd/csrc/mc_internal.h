@@ -23,6 +23,10 @@ enum {
     MC_CNT_SCORE_TOO_LONG = 7 // passwords longer than mc_score_words' max_len
 };
 
+#define MC_CK_POS1(h) (h)
+#define MC_CK_POS2(h) ((((h) ^ ((h) >> 29)) * 0x9E3779B97F4A7C15ull) >> 21)
+#define MC_CK_TAG(h, n) ((uint32_t)((h) >> 32) ^ ((uint32_t)(n) * 0x9E3779B1u))
+
 struct mc_table {
     uint32_t kind, order, n_ctx, n_sym;
     uint64_t n_ent;
@@ -42,6 +46,10 @@ struct mc_table {
     std::vector<uint32_t> sym_chars;
     std::vector<mc_payload> dense;        // [n_ctx][n_sym] resolved transitions (small single-character alphabets)
     std::vector<mc_slot> wordhash;        // empty when the descriptor had no symbol text
+    // the same map as a two-choice table of 8-byte slots (tag << 32 | symbol) for look-ups that must end in ONE round
+    // of loads (k_score_words_fast): a text's slot is MC_CK_POS1 or MC_CK_POS2 of its hash; a tag that matches is
+    // checked against the symbol's text by the caller.  Empty slots are ~0; empty vector: none could be built
+    std::vector<uint64_t> wordck;
     std::vector<uint32_t> sym_text_off, sym_text;
     uint32_t max_word_len, start_sym;
     // MC_KIND_BPE

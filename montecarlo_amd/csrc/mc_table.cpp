@@ -490,7 +490,8 @@ extern "C" int mc_table_compile(const mc_model_desc *d, mc_table **out) {
     if (d->sym_text_off) {
         t->sym_text_off.assign(d->sym_text_off, d->sym_text_off + d->n_sym + 1);
         t->sym_text.assign(d->sym_text, d->sym_text + d->sym_text_off[d->n_sym]);
-        uint64_t wcap = pow2ceil(std::max<uint64_t>(16, 2ull * d->n_sym));
+        // (a quarter full at most: a look-up of a text that is no symbol -- most of them -- ends at its first or second slot)
+        uint64_t wcap = pow2ceil(std::max<uint64_t>(16, 4ull * d->n_sym));
         t->wordhash.assign(wcap, mc_slot{~0ull, 0, 0});
         for (uint32_t s = 0; s < d->n_sym; ++s) {
             const uint32_t a = d->sym_text_off[s], n = d->sym_text_off[s + 1] - a;
@@ -510,6 +511,55 @@ extern "C" int mc_table_compile(const mc_model_desc *d, mc_table **out) {
                     return MC_ERR_TABLE;
                 }
             }
+        }
+    }
+
+    // the two-choice table of the same map: cuckoo insertion; a table that will not take every symbol within a few
+    // hundred moves is rebuilt at twice the size (a quarter full to begin with: in practice the first one does)
+    if (d->sym_text_off && !t->wordhash.empty()) {
+        auto hash_of = [&](uint32_t s) {
+            const uint32_t a = d->sym_text_off[s];
+            return mc_text_hash(d->sym_text + a, d->sym_text_off[s + 1] - a);
+        };
+        uint64_t ccap = pow2ceil(std::max<uint64_t>(16, 4ull * d->n_sym));
+        for (int attempt = 0; attempt < 5; ++attempt, ccap *= 2) {
+            const uint64_t mask = ccap - 1;
+            t->wordck.assign(ccap, ~0ull);
+            bool ok = true;
+            for (uint32_t s0 = 0; s0 < d->n_sym && ok; ++s0) {
+                if (d->sym_text_off[s0 + 1] == d->sym_text_off[s0]) continue;
+                uint32_t s = s0;
+                uint64_t h = hash_of(s);
+                auto item_of = [&](uint32_t sym, uint64_t hh) {
+                    return ((uint64_t)MC_CK_TAG(hh, d->sym_text_off[sym + 1] - d->sym_text_off[sym]) << 32) | sym;
+                };
+                const uint64_t p1 = MC_CK_POS1(h) & mask, p2 = MC_CK_POS2(h) & mask;
+                if (t->wordck[p1] == ~0ull) {
+                    t->wordck[p1] = item_of(s, h);
+                    continue;
+                }
+                if (t->wordck[p2] == ~0ull) {
+                    t->wordck[p2] = item_of(s, h);
+                    continue;
+                }
+                // take a slot; whoever sat there moves to its own other slot, and so on
+                uint64_t pos = p1;
+                ok = false;
+                for (int moves = 0; moves < 500; ++moves) {
+                    const uint32_t victim = (uint32_t)t->wordck[pos];
+                    t->wordck[pos] = item_of(s, h);
+                    s = victim;
+                    h = hash_of(s);
+                    pos = pos == (MC_CK_POS1(h) & mask) ? (MC_CK_POS2(h) & mask) : (MC_CK_POS1(h) & mask);
+                    if (t->wordck[pos] == ~0ull) {
+                        t->wordck[pos] = item_of(s, h);
+                        ok = true;
+                        break;
+                    }
+                }
+            }
+            if (ok) break;
+            t->wordck.clear();
         }
     }
 
@@ -648,6 +698,7 @@ size_t mc_table_device_bytes(const mc_table *t) {
            align256(t->payload.size() * sizeof(mc_payload)) +
            align256(t->trans.size() * sizeof(mc_slot)) + align256(t->ctxhash.size() * sizeof(mc_slot)) +
            align256(t->sym_chars.size() * sizeof(uint32_t)) + align256(t->wordhash.size() * sizeof(mc_slot)) +
+           align256(t->wordck.size() * sizeof(uint64_t)) +
            align256(t->sym_text_off.size() * sizeof(uint32_t)) + align256(t->sym_text.size() * sizeof(uint32_t)) +
            align256((size_t)MC_STATUS_SLOTS * MC_STATUS_STRIDE * sizeof(uint64_t)) + align256(t->dense.size() * sizeof(mc_payload)) +
            align256(t->seg_off.size() * 4) + align256(t->seg_row.size() * 4) + align256(t->seg_len.size() * 4) +

@@ -154,3 +154,41 @@ def test_injected_uniforms_on_multichar_alphabets(train_tab):
     device_samples(m, golden("nwords_n3_tab.json"), n=300, injected=True)
     m = BackWordsMonteCarlo(synth.as_file(train_tab), splitter="\t", threshold=3)
     device_samples(m, golden("backwords_thr3_tab.json"), n=300, injected=True)
+
+
+def test_subword_scoring_kernels_agree():
+    """mc_score_words' two kernels on the same inputs: k_score_words_fast (short passwords: characters in LDS, one
+    round of loads per position from the two-choice symbol table, tail calls) against k_score_words (the DFS as
+    written, mc_score_words_debug_kernel(1)): values bit for bit, split masks, the counters of transition probes and
+    steps -- for iter_max 1, 2, 7 and unbounded, with passwords up to the fast kernel's limit (31 characters + the
+    end symbol), past it (the launch falls back for the whole batch), empty, and out of the model."""
+    from montecarlo_amd import _native as nv
+    sub = synth.subword_corpus(30000)
+    m = BackWordsMonteCarlo(synth.as_file(sub), splitter="\t", threshold=10)
+    base = list(dict.fromkeys("".join(line.split("\t")) for line in synth.subword_corpus(30000, stream=2)))
+    rng = np.random.default_rng(11)
+    pw = base[:12000] + ["", "a", "~", "\x03"]
+    for s in base[:4000]:                                     # longer ones: two or three passwords glued together
+        t = s + base[int(rng.integers(0, len(base)))] + base[int(rng.integers(0, len(base)))]
+        pw.append(t[:31])
+    pw.append((base[0] * 8)[:31])
+    for limit, expect_fast in ((31, True), (40, False)):
+        batch = pw if limit == 31 else pw + [(base[1] * 10)[:40]]
+        cps, off, max_len = m._flat.encode_text(batch)
+        assert max_len == limit
+        for iter_max in (1, 2, 7, 10 ** 35):
+            res = {}
+            for which in (0, 1):
+                nv.lib.mc_score_words_debug_kernel(which)
+                try:
+                    m._dev.check()
+                    ml2p, split = m._dev.score_words(cps, off, max_len, iter_max)
+                    cnt = m._dev.check()
+                finally:
+                    nv.lib.mc_score_words_debug_kernel(0)
+                res[which] = (ml2p.cpu().numpy(), split.cpu().numpy(), cnt["score_probes"], cnt["score_steps"])
+            assert np.array_equal(bits(res[0][0]), bits(res[1][0])), (limit, iter_max)
+            assert np.array_equal(res[0][1], res[1][1]), (limit, iter_max)
+            assert res[0][2:] == res[1][2:], (limit, iter_max)
+            assert (res[0][0] < 1022.0).sum() > 10000
+    assert expect_fast is False

@@ -64,6 +64,31 @@ try:
                           f"native sources than this tree's")
 except (OSError, ValueError):
     pass
+# The same for k_sample's vector-ALU counters (profiles/valu_latest.json: scripts/valu_pass.sh, one rocprofv3 --pmc pass
+# of this command and one of scripts/ubench/philox_mul as the yardstick; scripts/valu_summary.py says how they combine)
+VALU = {"measured": None, "why": "profiles/valu_latest.json absent"}
+try:
+    with open(os.path.join(ROOT, "profiles", "valu_latest.json")) as _f:
+        _v = json.load(_f)
+    from montecarlo_amd.build import sources_digest  # noqa: E402
+    if _v.get("csrc_sha256") and _v["csrc_sha256"] == sources_digest():
+        _k = _v["k_sample_alone"]
+        VALU = {"measured": _v.get("source"), "commit": str(_v.get("commit"))[:12],
+                "busy": _k.get("valu_busy_by_mix"), "busy_bounds": [_k["valu_busy_vs_no_multiplies"], _k["valu_busy"]],
+                "lanes_active": _k["lanes_active"], "wave_instructions_per_launch": _k["SQ_INSTS_VALU"],
+                "scalar_instructions_per_launch": _k["SQ_INSTS_SALU"],
+                "instructions_per_loop_iteration": {"valu": _k.get("valu_instructions_per_iteration"),
+                                                    "salu": _k.get("salu_instructions_per_iteration")},
+                "cycles_per_instruction": _v.get("cycles_per_instruction"),
+                "what": "k_sample alone (the launches of roofline.alone); busy = the SIMDs' vector-ALU time over the "
+                        "kernel's, pricing its own mix of v_mad_u64_u32 and other instructions at what "
+                        "scripts/ubench/philox_mul costs per instruction at 8 waves a SIMD in the same --pmc pass; "
+                        "bounds: against that loop without / with its multiplies"}
+    else:
+        VALU = {"measured": None, "why": f"stale: {_v.get('source')} was measured at commit {str(_v.get('commit'))[:12]} "
+                                         f"on other native sources than this tree's"}
+except (OSError, ValueError, KeyError):
+    pass
 # algorithmic bytes of k_sample: one 16-B draw-table record per draw, one more 16-B
 # record for a draw whose bucket straddles a threshold, 8 B per threshold read from RCUM (counted
 # from the compare counter: an upper bound, single-threshold buckets compare without a read),
@@ -73,6 +98,13 @@ B_DRAW, B_INDIRECT, B_PROBE, B_SAMPLE = 16, 16, 8, 8
 # distinct value.  Expanded arrays (--rank-index sorted): every key read once and written once in order (16 B), weight
 # sums read it again (8 B), positions read it and write the running sum (16 B)
 B_RANK_RUNS_KEY, B_RANK_RUNS_VALUE, B_RANK = 8, 24, 40
+
+
+class _NoMark:
+    """An event nobody reads: recording it is skipped (bench.py --time-every)."""
+    @staticmethod
+    def record(stream=None):
+        pass
 
 
 def C_vp(t):
@@ -151,6 +183,9 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the legs after the timed region that run BASELINE configs 3, 4, 5 and the sub-word "
                          "scorer once at their per-GPU sizes (`other_configs` in the JSON line; about a minute)")
+    ap.add_argument("--time-every", type=int, default=1,
+                    help="record the stage events (stage_ms, the roofline's kernel_ms) in every K-th timed step only: "
+                         "each recorded event is a host call and a barrier packet on the queue")
     ap.add_argument("--dump-last", default="",
                     help="rank 0 writes what the host received from the last timed step (guess numbers, how many of "
                          "them fit int64, order, sorted scores) to this .npz (tests/test_gpu_bench_modes.py)")
@@ -246,7 +281,10 @@ def main():
         """sample -> rank build -> [score -> order] -> queries -> guess numbers; the bracketed part runs on a
         second stream from the start of the step unless --serial; the guess numbers reach the host with the
         next step's sampling launch (--d2h)."""
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(12)]
+        if timed:
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(12)]
+        else:                                                # (only what orders the streams)
+            marks = [torch.cuda.Event() if i in (0, 6, 8, 11) else _NoMark for i in range(12)]
         slot = it & 1
         first = first_id(it, world, rank, N)                # disjoint Philox sample ids per rank and step
         marks[0].record()
@@ -387,7 +425,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        step(args.warmup + s, True)
+        step(args.warmup + s, s % args.time_every == 0)
     flush_carry()
     issued = time.perf_counter() - t0                       # the host's share: launching, not waiting
     fence()
@@ -525,7 +563,7 @@ def main():
             # the longest single launch; HBM traffic from profiles/*pmc_hbm_traffic.json (rocprofv3 --pmc)
             "roofline": {"bound": "hbm", "kernel": "k_sample", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC.get("k_sample"),
-                         "traffic_source": TRAFFIC_SOURCE,
+                         "traffic_source": TRAFFIC_SOURCE, "valu": VALU,
                          "bytes_per_launch": bytes_per_launch, "kernel_ms": ms["sample"],
                          "note": "timed inside the step: the copy workgroups of mc_sample_carry and the second "
                                  "stream's launches share the GPU with it" if side is not None else "",

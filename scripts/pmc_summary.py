@@ -71,8 +71,9 @@ def per_stage(rs):
         if stage is None or base.startswith("at::") or "rocclr_copy" in base:
             continue
         tot[stage] += v
-XX
-        elif base == "k_order_out":
+        if base in ("k_positions", "k_rl_final"):
+            stage = "after_rank_build"
+        elif base.startswith("k_order_out"):
             stage = "after_order"
     return tot, steps
 

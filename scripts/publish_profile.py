@@ -22,15 +22,24 @@ def main(tag, name):
                  ("kernel_stats.csv", "kernel_stats.csv"), ("pmc_summary.json", "pmc_hbm_traffic.json")):
         if os.path.exists(os.path.join(src, a)):
             shutil.copy(os.path.join(src, a), os.path.join(dst, f"{name}_{b}"))
+    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
+    dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "montecarlo_amd/csrc", "include"],
+                           capture_output=True, text=True).stdout.strip()
+    valu = os.path.join(src, "valu_summary.json")           # (scripts/valu_pass.sh)
+    if os.path.exists(valu):
+        v = json.load(open(valu))
+        if v.get("csrc_sha256") != sources_digest():
+            sys.exit("the native sources changed since the VALU passes: measure again before publishing")
+        v["commit"] = head + (" + uncommitted changes under csrc/ (the digest is of those)" if dirty else "")
+        v["source"] = f"profiles/{name}_valu.json"
+        for target in (f"{name}_valu.json", "valu_latest.json"):
+            json.dump(v, open(os.path.join(dst, target), "w"), indent=1)
     pmc = os.path.join(src, "pmc_summary.json")
     if not os.path.exists(pmc):
         return
     per_step = json.load(open(pmc)).get("_per_step")
     if not per_step:
         sys.exit("no per-step traffic in " + pmc)
-    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
-    dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "montecarlo_amd/csrc", "include"],
-                           capture_output=True, text=True).stdout.strip()
     if per_step.get("csrc_sha256") != sources_digest():
         sys.exit("the native sources changed since the measurement: measure again before publishing")
     per_step["commit"] = head + (" + uncommitted changes under csrc/ (the digest below is of those)" if dirty else "")

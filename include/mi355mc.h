@@ -398,6 +398,10 @@ void mc_score_words_debug_kernel(int which);
  * order and is not reproduced; no model of finite probabilities reaches it.) */
 int mc_score_bpe(mc_model *m, const uint32_t *cps, const uint8_t *cls, const uint64_t *off, uint64_t count,
                  double *out_ml2p, void *stream);
+/* Test / measurement hook, as mc_score_words_debug_kernel: 0 (default) k_score_bpe_fast (passwords of at most 32
+ * characters a load round after another, longer ones inside the same launch as k_score_bpe walks them), 1 k_score_bpe
+ * always (one load after another).  Same values.  Environment MC_SCORE_BPE_KERNEL=walk does the same for a process. */
+void mc_score_bpe_debug_kernel(int which);
 
 /* ---- rank estimation: MonteCarloLib.__init__ (lib4mc/MonteCarloLib.py:10-28): sort the
  * sampled -log2 p ascending, positions = cumsum(2^(key - log2 n_global)).  keys_sorted and

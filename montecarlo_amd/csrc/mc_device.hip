@@ -1073,7 +1073,111 @@ __global__ void __launch_bounds__(256) k_sample_bpe(DevModel m, SampleArgs a) {
     }
 }
 
-// BpePcfgSim.calc_ml2p (bpe_simulator.py:118-150), one lane per password.
+// BpePcfgSim.calc_ml2p (bpe_simulator.py:118-150) for one password, one load after another (the walk as written:
+// k_score_bpe, and k_score_bpe_fast for passwords longer than its LDS rows)
+__device__ double bpe_score_one(const DevModel &m, const uint32_t *__restrict__ cps, const uint8_t *__restrict__ cls,
+                                unsigned long long p0, uint32_t len, unsigned int &c_probe, unsigned int &c_step) {
+    // luds (:17-40): runs of equal class; hashed as the label index hashes its units (mc_ctx_hash).
+    // luds of "" is ((" ", 0),): no structure has that label, and no structure has total length 0.
+    uint32_t n_units = 0;
+    for (uint32_t j = 0; j < len; ++j)
+        if (j == 0 || cls[p0 + j] != cls[p0 + j - 1]) ++n_units;
+    unsigned long long h = 0x9E3779B97F4A7C15ull ^ ((unsigned long long)n_units << 32);
+    for (uint32_t j = 0; j < len;) {
+        uint32_t e = j + 1;
+        while (e < len && cls[p0 + e] == cls[p0 + j]) ++e;
+        const uint32_t unit = ((uint32_t)cls[p0 + j] << 24) | (e - j);
+        h = mix64(h ^ ((unsigned long long)unit + 0x632BE59BD9B4E019ull));
+        j = e;
+    }
+    if (h == ~0ull) h = ~0ull - 1;
+    const uint32_t *cand = nullptr;
+    uint32_t n_cand = 0;
+    if (len > 0 && m.lab_mask) {
+        for (unsigned long long q = h & m.lab_mask;; q = (q + 1) & m.lab_mask) {
+            const Slot sl = m.labhash[q];
+            if (sl.key == ~0ull) break;
+            if (sl.key == h && sl.pad == n_units) {
+                const uint32_t *u = m.lab_units + m.lab_off[sl.val];
+                bool same = true;
+                uint32_t ui = 0;
+                for (uint32_t j = 0; j < len && same;) {
+                    uint32_t e = j + 1;
+                    while (e < len && cls[p0 + e] == cls[p0 + j]) ++e;
+                    same = u[ui++] == (((uint32_t)cls[p0 + j] << 24) | (e - j));
+                    j = e;
+                }
+                if (same) {
+                    cand = m.lab_cand + m.lab_cand_off[sl.val];
+                    n_cand = m.lab_cand_off[sl.val + 1] - m.lab_cand_off[sl.val];
+                    break;
+                }
+            }
+        }
+    }
+    if (n_cand == 0)  // :122-125: fall back to the mixed-tag structures of the same total length
+        for (uint32_t k = 0; k < m.n_np; ++k)
+            if (m.np_len[k] == len) {
+                cand = m.np_cand + m.np_off[k];
+                n_cand = m.np_off[k + 1] - m.np_off[k];
+                break;
+            }
+    double best = 1022.0;
+    for (uint32_t c = 0; c < n_cand; ++c) {
+        const uint32_t st = cand[c];
+        double p = m.payload[st].ml2p;  // grammars[candidate]: row 0 starts at entry 0
+        uint32_t start = 0;
+        bool ok = true;
+        for (uint32_t k = m.seg_off[st]; k < m.seg_off[st + 1]; ++k) {
+            const uint32_t row = m.seg_row[k], tl = m.seg_len[k];
+            // replacement = pwd[start:start + t_len]  (slicing clamps at the end of the string)
+            const uint32_t b = start < len ? start : len, e = start + tl < len ? start + tl : len;
+            start += tl;
+            uint32_t sym = MC_NONE;
+            if (row != MC_NONE && e > b) {
+                unsigned long long hh = 0xCBF29CE484222325ull;
+                for (uint32_t j = b; j < e; ++j) hh = (hh ^ cps[p0 + j]) * 0x100000001B3ull;
+                if (hh == ~0ull) hh = ~0ull - 1;
+                for (unsigned long long q = hh & m.word_mask;; q = (q + 1) & m.word_mask) {
+                    const Slot sl = m.wordhash[q];
+                    if (sl.key == ~0ull) break;
+                    if (sl.key == hh && sl.pad == e - b) {
+                        const uint32_t *txt = m.sym_text + m.sym_text_off[sl.val];
+                        bool same = true;
+                        for (uint32_t j = 0; j < e - b; ++j) same = same && txt[j] == cps[p0 + b + j];
+                        if (same) {
+                            sym = sl.val;
+                            break;
+                        }
+                    }
+                }
+            }
+            uint32_t ent = MC_NONE;
+            if (sym != MC_NONE) {
+                const unsigned long long key = ((unsigned long long)row << 32) | sym;
+                for (unsigned long long q = mix64(key + 0x9E3779B97F4A7C15ull) & m.trans_mask;;
+                     q = (q + 1) & m.trans_mask) {
+                    const Slot sl = m.trans[q];
+                    ++c_probe;
+                    if (sl.key == key) {
+                        ent = sl.val;
+                        break;
+                    }
+                    if (sl.key == ~0ull) break;
+                }
+            }
+            if (ent == MC_NONE) {  // replacement not in terminal (:139-141)
+                ok = false;
+                break;
+            }
+            p += m.payload[ent].ml2p;
+            ++c_step;
+        }
+        if (ok && p < 1022.0 && p < best) best = p;
+    }
+    return best;
+}
+
 __global__ void __launch_bounds__(256) k_score_bpe(DevModel m, const uint32_t *__restrict__ cps,
                                                    const uint8_t *__restrict__ cls,
                                                    const unsigned long long *__restrict__ off, unsigned long long count,
@@ -1082,40 +1186,109 @@ __global__ void __launch_bounds__(256) k_score_bpe(DevModel m, const uint32_t *_
     for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < count;
          t += (unsigned long long)gridDim.x * blockDim.x) {
         const unsigned long long p0 = off[t];
-        const uint32_t len = (uint32_t)(off[t + 1] - p0);
-        // luds (:17-40): runs of equal class; hashed as the label index hashes its units (mc_ctx_hash).
-        // luds of "" is ((" ", 0),): no structure has that label, and no structure has total length 0.
-        uint32_t n_units = 0;
-        for (uint32_t j = 0; j < len; ++j)
-            if (j == 0 || cls[p0 + j] != cls[p0 + j - 1]) ++n_units;
-        unsigned long long h = 0x9E3779B97F4A7C15ull ^ ((unsigned long long)n_units << 32);
-        for (uint32_t j = 0; j < len;) {
-            uint32_t e = j + 1;
-            while (e < len && cls[p0 + e] == cls[p0 + j]) ++e;
-            const uint32_t unit = ((uint32_t)cls[p0 + j] << 24) | (e - j);
-            h = mix64(h ^ ((unsigned long long)unit + 0x632BE59BD9B4E019ull));
-            j = e;
+        out[t] = bpe_score_one(m, cps, cls, p0, (uint32_t)(off[t + 1] - p0), c_probe, c_step);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        c_probe += __shfl_down(c_probe, o);
+        c_step += __shfl_down(c_step, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&status_slot(m)[MC_CNT_SCORE_PROBES], (unsigned long long)c_probe);
+        atomicAdd(&status_slot(m)[MC_CNT_SCORE_STEPS], (unsigned long long)c_step);
+    }
+}
+
+// ---- the same for passwords of at most BF_MAX characters, a load ROUND after another: characters and classes in LDS
+// (class << 24 | code point at s_cc[j * 256]), the class runs from a bit mask of their first characters, the label's
+// units compared in one round, and per candidate structure the segments four at a time: their rows and lengths, both
+// slots of every terminal in the two-choice symbol table, the transitions' first probes beside the texts' offsets, the
+// payloads beside the texts -- five rounds where the walk above makes some fifty dependent loads.  Same sums in the
+// same order.  A terminal whose text differs from the hit's (two texts, one hash) is looked up again probe by probe.
+constexpr uint32_t BF_MAX = 32, BF_SEG = 4;
+
+__device__ __forceinline__ uint32_t bf_unit(const uint32_t *s_cc, uint32_t &rem, uint32_t len) {  // the next class run
+    const uint32_t s0 = (uint32_t)__ffs(rem) - 1u;
+    rem &= rem - 1u;
+    const uint32_t e0 = rem ? (uint32_t)__ffs(rem) - 1u : len;
+    return (s_cc[s0 * 256u] & 0xFF000000u) | (e0 - s0);
+}
+
+__device__ __forceinline__ uint32_t bf_find_trans(const DevModel &m, uint32_t row, uint32_t sym, unsigned int &c_probe) {
+    const unsigned long long key = ((unsigned long long)row << 32) | sym;
+    for (unsigned long long q = mix64(key + 0x9E3779B97F4A7C15ull) & m.trans_mask;; q = (q + 1) & m.trans_mask) {
+        const Slot sl = m.trans[q];
+        ++c_probe;
+        if (sl.key == key) return sl.val;
+        if (sl.key == ~0ull) return MC_NONE;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_score_bpe_fast(DevModel m, const uint32_t *__restrict__ cps,
+                                                        const uint8_t *__restrict__ cls,
+                                                        const unsigned long long *__restrict__ off,
+                                                        unsigned long long count, double *__restrict__ out) {
+    __shared__ uint32_t bf_lds[BF_MAX * 256];
+    uint32_t *const s_cc = bf_lds + threadIdx.x;
+    unsigned int c_probe = 0, c_step = 0;
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256u;
+    unsigned long long t = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
+    unsigned long long p0n = 0, p1n = 0;  // (a lane's next offsets are requested a password ahead)
+    if (t < count) {
+        p0n = off[t];
+        p1n = off[t + 1];
+    }
+    for (; t < count; t += stride) {
+        const unsigned long long p0 = p0n;
+        const uint32_t len = (uint32_t)(p1n - p0);
+        if (t + stride < count) {
+            p0n = off[t + stride];
+            p1n = off[t + stride + 1];
         }
+        if (len == 0 || len > BF_MAX) {
+            out[t] = bpe_score_one(m, cps, cls, p0, len, c_probe, c_step);
+            continue;
+        }
+        uint32_t bm = 0, prev = ~0u;  // bit j: character j starts a class run (luds, :17-40)
+        for (uint32_t j0 = 0; j0 < len; j0 += 8) {
+            uint32_t c[8], k[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                c[u] = j0 + u < len ? cps[p0 + j0 + u] : 0u;
+                k[u] = j0 + u < len ? (uint32_t)cls[p0 + j0 + u] : 0u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u)
+                if (j0 + u < len) {
+                    s_cc[(j0 + u) * 256u] = (k[u] << 24) | c[u];
+                    bm |= (k[u] != prev ? 1u : 0u) << (j0 + u);
+                    prev = k[u];
+                }
+        }
+        const uint32_t n_units = (uint32_t)__popc(bm);
+        unsigned long long h = 0x9E3779B97F4A7C15ull ^ ((unsigned long long)n_units << 32);
+        for (uint32_t rem = bm; rem;) h = mix64(h ^ ((unsigned long long)bf_unit(s_cc, rem, len) + 0x632BE59BD9B4E019ull));
         if (h == ~0ull) h = ~0ull - 1;
         const uint32_t *cand = nullptr;
         uint32_t n_cand = 0;
-        if (len > 0 && m.lab_mask) {
+        if (m.lab_mask) {
             for (unsigned long long q = h & m.lab_mask;; q = (q + 1) & m.lab_mask) {
                 const Slot sl = m.labhash[q];
                 if (sl.key == ~0ull) break;
                 if (sl.key == h && sl.pad == n_units) {
-                    const uint32_t *u = m.lab_units + m.lab_off[sl.val];
-                    bool same = true;
-                    uint32_t ui = 0;
-                    for (uint32_t j = 0; j < len && same;) {
-                        uint32_t e = j + 1;
-                        while (e < len && cls[p0 + e] == cls[p0 + j]) ++e;
-                        same = u[ui++] == (((uint32_t)cls[p0 + j] << 24) | (e - j));
-                        j = e;
+                    const uint32_t lo = m.lab_off[sl.val], c0 = m.lab_cand_off[sl.val], c1 = m.lab_cand_off[sl.val + 1];
+                    const uint32_t *un = m.lab_units + lo;
+                    uint32_t diff = 0, rem = bm;
+                    for (uint32_t k0 = 0; k0 < n_units; k0 += 8) {
+                        uint32_t uu[8];
+#pragma unroll
+                        for (uint32_t i = 0; i < 8; ++i) uu[i] = k0 + i < n_units ? un[k0 + i] : 0u;
+#pragma unroll
+                        for (uint32_t i = 0; i < 8; ++i)
+                            if (k0 + i < n_units) diff |= uu[i] ^ bf_unit(s_cc, rem, len);
                     }
-                    if (same) {
-                        cand = m.lab_cand + m.lab_cand_off[sl.val];
-                        n_cand = m.lab_cand_off[sl.val + 1] - m.lab_cand_off[sl.val];
+                    if (!diff) {
+                        cand = m.lab_cand + c0;
+                        n_cand = c1 - c0;
                         break;
                     }
                 }
@@ -1132,52 +1305,113 @@ __global__ void __launch_bounds__(256) k_score_bpe(DevModel m, const uint32_t *_
         for (uint32_t c = 0; c < n_cand; ++c) {
             const uint32_t st = cand[c];
             double p = m.payload[st].ml2p;  // grammars[candidate]: row 0 starts at entry 0
+            const uint32_t k0 = m.seg_off[st], k1 = m.seg_off[st + 1];
             uint32_t start = 0;
             bool ok = true;
-            for (uint32_t k = m.seg_off[st]; k < m.seg_off[st + 1]; ++k) {
-                const uint32_t row = m.seg_row[k], tl = m.seg_len[k];
-                // replacement = pwd[start:start + t_len]  (slicing clamps at the end of the string)
-                const uint32_t b = start < len ? start : len, e = start + tl < len ? start + tl : len;
-                start += tl;
-                uint32_t sym = MC_NONE;
-                if (row != MC_NONE && e > b) {
-                    unsigned long long hh = 0xCBF29CE484222325ull;
-                    for (uint32_t j = b; j < e; ++j) hh = (hh ^ cps[p0 + j]) * 0x100000001B3ull;
-                    if (hh == ~0ull) hh = ~0ull - 1;
-                    for (unsigned long long q = hh & m.word_mask;; q = (q + 1) & m.word_mask) {
-                        const Slot sl = m.wordhash[q];
-                        if (sl.key == ~0ull) break;
-                        if (sl.key == hh && sl.pad == e - b) {
-                            const uint32_t *txt = m.sym_text + m.sym_text_off[sl.val];
-                            bool same = true;
-                            for (uint32_t j = 0; j < e - b; ++j) same = same && txt[j] == cps[p0 + b + j];
-                            if (same) {
-                                sym = sl.val;
-                                break;
+            for (uint32_t kb = k0; kb < k1 && ok; kb += BF_SEG) {
+                uint32_t row[BF_SEG], tl[BF_SEG], bb[BF_SEG], ee[BF_SEG], sym[BF_SEG], ent[BF_SEG], toff[BF_SEG], diff[BF_SEG];
+                unsigned long long key[BF_SEG], s1[BF_SEG], s2[BF_SEG];
+                Slot ts[BF_SEG];
+                double pl[BF_SEG];
+#pragma unroll
+                for (uint32_t i = 0; i < BF_SEG; ++i) {
+                    row[i] = kb + i < k1 ? m.seg_row[kb + i] : MC_NONE;
+                    tl[i] = kb + i < k1 ? m.seg_len[kb + i] : 0u;
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < BF_SEG; ++i) {
+                    // replacement = pwd[start:start + t_len]  (slicing clamps at the end of the string)
+                    bb[i] = start < len ? start : len;
+                    ee[i] = start + tl[i] < len ? start + tl[i] : len;
+                    start += tl[i];
+                    sym[i] = ent[i] = MC_NONE;
+                    diff[i] = 0;
+                    key[i] = 0;
+                    if (row[i] != MC_NONE && ee[i] > bb[i]) {
+                        unsigned long long hh = FNV_BASIS;
+                        for (uint32_t j = bb[i]; j < ee[i]; ++j) hh = (hh ^ (s_cc[j * 256u] & 0xFFFFFFu)) * FNV_PRIME;
+                        key[i] = hh == ~0ull ? ~0ull - 1 : hh;
+                        s1[i] = m.wordck[MC_CK_POS1(key[i]) & m.wordck_mask];
+                        s2[i] = m.wordck[MC_CK_POS2(key[i]) & m.wordck_mask];
+                    }
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < BF_SEG; ++i)
+                    if (row[i] != MC_NONE && ee[i] > bb[i]) {
+                        const uint32_t tag = MC_CK_TAG(key[i], ee[i] - bb[i]);
+                        if ((uint32_t)(s1[i] >> 32) == tag && (uint32_t)s1[i] != MC_NONE) sym[i] = (uint32_t)s1[i];
+                        else if ((uint32_t)(s2[i] >> 32) == tag && (uint32_t)s2[i] != MC_NONE) sym[i] = (uint32_t)s2[i];
+                    }
+#pragma unroll
+                for (uint32_t i = 0; i < BF_SEG; ++i)
+                    if (sym[i] != MC_NONE) {
+                        const unsigned long long tk = ((unsigned long long)row[i] << 32) | sym[i];
+                        ts[i] = m.trans[mix64(tk + 0x9E3779B97F4A7C15ull) & m.trans_mask];
+                        toff[i] = m.sym_text_off[sym[i]];
+                    }
+#pragma unroll
+                for (uint32_t i = 0; i < BF_SEG; ++i)
+                    if (sym[i] != MC_NONE) {
+                        const unsigned long long tk = ((unsigned long long)row[i] << 32) | sym[i];
+                        ++c_probe;
+                        if (ts[i].key == tk) {
+                            ent[i] = ts[i].val;
+                        } else if (ts[i].key != ~0ull) {  // (another key in the first slot: the walk goes on)
+                            for (unsigned long long q = (mix64(tk + 0x9E3779B97F4A7C15ull) + 1) & m.trans_mask;;
+                                 q = (q + 1) & m.trans_mask) {
+                                const Slot sl = m.trans[q];
+                                ++c_probe;
+                                if (sl.key == tk) {
+                                    ent[i] = sl.val;
+                                    break;
+                                }
+                                if (sl.key == ~0ull) break;
                             }
                         }
                     }
-                }
-                uint32_t ent = MC_NONE;
-                if (sym != MC_NONE) {
-                    const unsigned long long key = ((unsigned long long)row << 32) | sym;
-                    for (unsigned long long q = mix64(key + 0x9E3779B97F4A7C15ull) & m.trans_mask;;
-                         q = (q + 1) & m.trans_mask) {
-                        const Slot sl = m.trans[q];
-                        ++c_probe;
-                        if (sl.key == key) {
-                            ent = sl.val;
-                            break;
+#pragma unroll
+                for (uint32_t i = 0; i < BF_SEG; ++i) {
+                    pl[i] = m.payload[ent[i] == MC_NONE ? 0u : ent[i]].ml2p;
+                    if (sym[i] != MC_NONE) {
+                        const uint32_t n = ee[i] - bb[i];
+                        for (uint32_t j0 = 0; j0 < n; j0 += 8) {
+                            uint32_t tx[8];
+#pragma unroll
+                            for (uint32_t u = 0; u < 8; ++u) tx[u] = j0 + u < n ? m.sym_text[toff[i] + j0 + u] : 0u;
+#pragma unroll
+                            for (uint32_t u = 0; u < 8; ++u)
+                                if (j0 + u < n) diff[i] |= tx[u] ^ (s_cc[(bb[i] + j0 + u) * 256u] & 0xFFFFFFu);
                         }
-                        if (sl.key == ~0ull) break;
                     }
                 }
-                if (ent == MC_NONE) {  // replacement not in terminal (:139-141)
-                    ok = false;
-                    break;
+#pragma unroll
+                for (uint32_t i = 0; i < BF_SEG; ++i) {
+                    if (!ok || kb + i >= k1) continue;
+                    if (diff[i]) {  // the hit's text is another one's: the terminal is looked up again, probe by probe
+                        ent[i] = MC_NONE;
+                        const uint32_t n = ee[i] - bb[i];
+                        for (unsigned long long q = key[i] & m.word_mask;; q = (q + 1) & m.word_mask) {
+                            const Slot sl = m.wordhash[q];
+                            if (sl.key == ~0ull) break;
+                            if (sl.key == key[i] && sl.pad == n) {
+                                const uint32_t *txt = m.sym_text + m.sym_text_off[sl.val];
+                                bool same = true;
+                                for (uint32_t j = 0; j < n; ++j) same = same && txt[j] == (s_cc[(bb[i] + j) * 256u] & 0xFFFFFFu);
+                                if (same) {
+                                    ent[i] = bf_find_trans(m, row[i], sl.val, c_probe);
+                                    break;
+                                }
+                            }
+                        }
+                        pl[i] = m.payload[ent[i] == MC_NONE ? 0u : ent[i]].ml2p;
+                    }
+                    if (ent[i] == MC_NONE) {  // replacement not in terminal (:139-141)
+                        ok = false;
+                    } else {
+                        p += pl[i];
+                        ++c_step;
+                    }
                 }
-                p += m.payload[ent].ml2p;
-                ++c_step;
             }
             if (ok && p < 1022.0 && p < best) best = p;
         }
@@ -1667,6 +1901,9 @@ extern "C" int mc_score_words(mc_model *m, const uint32_t *cps, const uint64_t *
     return MC_OK;
 }
 
+static std::atomic<int> g_bpe_kernel{0};
+extern "C" void mc_score_bpe_debug_kernel(int which) { g_bpe_kernel.store(which); }
+
 extern "C" int mc_score_bpe(mc_model *m, const uint32_t *cps, const uint8_t *cls, const uint64_t *off, uint64_t count,
                             double *out_ml2p, void *stream) {
     if (!m || (count && (!off || !out_ml2p))) {
@@ -1678,10 +1915,17 @@ extern "C" int mc_score_bpe(mc_model *m, const uint32_t *cps, const uint8_t *cls
         mc_set_error("mc_score_bpe: not a BPE-PCFG model");
         return MC_ERR_ARG;
     }
-    unsigned long long want = (count + 255) / 256, cap = (unsigned long long)m->n_cu * 8;
+    static const bool walk_env = getenv("MC_SCORE_BPE_KERNEL") && !strcmp(getenv("MC_SCORE_BPE_KERNEL"), "walk");
+    const bool fast = !walk_env && g_bpe_kernel.load() != 1 && m->dev.wordck;
+    // (k_score_bpe_fast: 32 KB of LDS and 113 VGPRs: four workgroups share a CU)
+    unsigned long long want = (count + 255) / 256, cap = (unsigned long long)m->n_cu * (fast ? 4 : 8);
     dim3 g((unsigned)(want < cap ? want : cap)), b(256);
-    hipLaunchKernelGGL(k_score_bpe, g, b, 0, (hipStream_t)stream, m->dev, cps, cls, (const unsigned long long *)off,
-                       (unsigned long long)count, out_ml2p);
+    if (fast)
+        hipLaunchKernelGGL(k_score_bpe_fast, g, b, 0, (hipStream_t)stream, m->dev, cps, cls, (const unsigned long long *)off,
+                           (unsigned long long)count, out_ml2p);
+    else
+        hipLaunchKernelGGL(k_score_bpe, g, b, 0, (hipStream_t)stream, m->dev, cps, cls, (const unsigned long long *)off,
+                           (unsigned long long)count, out_ml2p);
     HIP_TRY(hipGetLastError());
     return MC_OK;
 }

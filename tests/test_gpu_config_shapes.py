@@ -85,6 +85,20 @@ def test_bpe_config4_shape():
     reached = sum(1 for p, x in zip(pw, want)
                   if x < orc.UNPARSEABLE and orc.luds(p) not in o.converted)
     assert reached > 0
+    # both scoring kernels on the same batch (k_score_bpe_fast is what ran above; mc_score_bpe_debug_kernel(1): the
+    # walk, one load after another), with passwords at and past the fast kernel's 32 characters
+    from montecarlo_amd import _native as nv
+    longer = [(s * 6)[:n_] for s in uniq[:300] if s for n_ in (31, 32, 33, 47)]
+    cps, cls, off = m.encode(pw + longer)
+    nv.lib.mc_score_bpe_debug_kernel(1)
+    try:
+        walk = m._dev.score_bpe(cps, cls, off).cpu().numpy()
+    finally:
+        nv.lib.mc_score_bpe_debug_kernel(0)
+    fast = m._dev.score_bpe(cps, cls, off).cpu().numpy()
+    assert np.array_equal(bits(fast), bits(walk))
+    assert np.array_equal(bits(fast[:len(pw)]), bits(want))
+    assert np.array_equal(bits(fast[len(pw):]), bits([o.calc_ml2p(p) for p in longer]))
 
 
 def test_v2_n6_config3_model_matches_c_oracle():

@@ -19,7 +19,9 @@ from montecarlo_amd.build import sources_digest  # noqa: E402
 def main(tag, name):
     src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
     for a, b in (("bench.json", "bench.json"), ("bench_prof.json", "bench_under_profiler.json"),
-                 ("kernel_stats.csv", "kernel_stats.csv"), ("pmc_summary.json", "pmc_hbm_traffic.json")):
+                 ("kernel_stats.csv", "kernel_stats.csv"), ("pmc_summary.json", "pmc_hbm_traffic.json"),
+                 ("other_configs_kernel_stats.csv", "other_configs_kernel_stats.csv"),
+                 ("bench_others.json", "bench_other_configs_under_profiler.json")):
         if os.path.exists(os.path.join(src, a)):
             shutil.copy(os.path.join(src, a), os.path.join(dst, f"{name}_{b}"))
     head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()

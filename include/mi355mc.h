@@ -475,7 +475,13 @@ int mc_rank_build_noalloc(const double *keys_in, uint64_t n, uint64_t n_global, 
  *   info                         output (device uint64[8]): {D, error word, keys counted, heavy values, tail keys,
  *                                builds the list of heavy values has served, 0, 0}; the query reads D from it, so
  *                                nothing comes back to the host between build and query
- * Keys: non-negative doubles (as mc_rank_build), n <= mc_rank_runs_max_keys() = 2^26.  Keys that do not repeat
+ * Keys: non-negative doubles (as mc_rank_build).  mc_rank_runs_max_keys() = 2^26 is the size up to which the index
+ * is the host classes' default.  Beyond it and up to 2^32 - 1 keys mc_rank_runs_build works in two levels (the keys
+ * that are no copies of the sample's heavy values go to 64 value-range groups, each group is then built as above,
+ * all of them side by side, and the groups' runs are joined: nine launches); correct against mc_rank_build where it
+ * was tried (7e7 and 2e8 keys: tests/test_gpu_runs.py, scripts/runs_big_check.py) but not faster below 2e8 keys,
+ * and the 1.25e9 samples of the v2 6-gram model are refused (their highest value ranges hold a million keys that
+ * are all distinct): nothing takes it by default.  Keys that do not repeat
  * (more than 2048 distinct values in one of the 1024 equal parts of the value range: uniform random numbers) do
  * not suit the index: the build then marks it failed (error word set, D = 0, every query answers NaN) and
  * mc_rank_runs_check returns MC_ERR_UNSUITED -- the caller builds with mc_rank_build instead, which sorts anything
@@ -508,6 +514,10 @@ int mc_rank_runs_expand(const double *vals, const uint64_t *cum_count, const dou
  * ticks (100 MHz) their workgroups spend per phase to 16 device counters; out (may be NULL) receives the counters
  * gathered so far and clears them.  Synchronises the device. */
 int mc_rank_runs_debug_phases(int on, uint64_t out[16]);
+/* Development aid: for a build of more than 2^26 keys (two levels: 64 value-range groups), what every group
+ * received and made of it: out[9 g] = keys of group g, out[9 g + 1 .. 9 g + 8] = the info words of the group's own
+ * index.  `out` holds 64 * 9 words.  Waits for the stream. */
+int mc_rank_runs_debug_groups(const void *workspace, uint64_t n, uint64_t *out, void *stream);
 
 /* ml2p2rank (lib4mc/MonteCarloLib.py:30-32) for t queries: cnt = bisect_right(keys_sorted, x),
  * pos = positions[cnt-1] or 0.0 when cnt == 0 (the caller maps a global cnt of 0 to the

@@ -142,6 +142,7 @@ def _load() -> C.CDLL:
         "mc_rank_runs_query": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp]),
         "mc_rank_runs_expand": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.c_uint64, vp, vp, vp]),
         "mc_rank_runs_debug_phases": (C.c_int, [C.c_int, u64p]),
+        "mc_rank_runs_debug_groups": (C.c_int, [vp, C.c_uint64, u64p, vp]),
         "mc_score_words_debug_kernel": (None, [C.c_int]),
         "mc_score_bpe_debug_kernel": (None, [C.c_int]),
     }
@@ -196,7 +197,8 @@ EXPORTS = ["mc_abi_version", "mc_last_error", "mc_table_compile", "mc_table_free
            "mc_score", "mc_rank_workspace_bytes", "mc_rank_build", "mc_rank_check", "mc_rank_debug_fail", "mc_rank_debug_search", "mc_workspace_forget", "mc_rank_noalloc_max_keys", "mc_rank_build_noalloc", "mc_rank_query", "mc_order_workspace_bytes", "mc_order_keys", "mc_guess_numbers_workspace_bytes", "mc_guess_numbers", "mc_comm_unique_id", "mc_comm_init", "mc_allreduce_rank", "mc_comm_destroy", "mc_enumerate", "mc_enum_info", "mc_enum_fetch",
            "mc_enum_free", "mc_rank_runs_workspace_bytes", "mc_rank_runs_capacity", "mc_rank_runs_max_keys", "mc_rank_runs_build",
            "mc_rank_runs_forget", "mc_rank_runs_check", "mc_rank_runs_query", "mc_rank_runs_expand", "mc_rank_runs_debug_phases",
-           "mc_score_words_debug_kernel", "mc_score_bpe_debug_kernel"]
+           "mc_score_words_debug_kernel", "mc_score_bpe_debug_kernel",
+           "mc_rank_runs_debug_groups"]
 
 
 def check(rc: int) -> int:

@@ -40,6 +40,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 #include "mc_internal.h"
 
@@ -107,6 +108,9 @@ struct RWs {
     double *bin_w;   // [P_MAX] their weights
     u32 n, region, regions, nb, P;
     double logn;
+    // the look-up table of k_rl_sniff: a cell's bin follows, in these shares, the sample KEYS below it, the sample's
+    // DISTINCT values below it, and (the rest) its own place in the range.  0.25 / 0 for a build of up to 2^26 keys
+    double eq_share, eq_distinct;
     u32 reuse_list, debug_fail;
     // outputs (the caller's)
     u64 *out_vals, *out_ccum;
@@ -231,7 +235,7 @@ __device__ __forceinline__ bool sample_index(u32 n, u32 q, u64 &idx) {
     return true;
 }
 
-__global__ void __launch_bounds__(SNIFF_THREADS) k_rl_sniff(RWs w) {
+__device__ __forceinline__ void rl_sniff_body(const RWs &w) {
     constexpr int PER = SNIFF_S / SNIFF_THREADS;
     static_assert(SNIFF_SLOTS == 16384, "slot = top 14 bits of the mix");
     __shared__ u32 tag[SNIFF_SLOTS];     // 0 = empty
@@ -437,34 +441,63 @@ __global__ void __launch_bounds__(SNIFF_THREADS) k_rl_sniff(RWs w) {
     static_assert(SNIFF_SLOTS / 2 >= CELLS && SNIFF_SLOTS >= 2 * H_MAX + CELLS / 2, "the histogram borrows tc, the table borrows tag");
     u32 *hist = tc;                                        // (the ranks that lived here are dead after the barrier below)
     unsigned short *slut = (unsigned short *)(tag + 2 * H_MAX);  // (behind the sorted list)
-    __shared__ u32 wtot16[SNIFF_THREADS / 64];
+    __shared__ u32 wtot16[SNIFF_THREADS / 64], wtotd[SNIFF_THREADS / 64];
+    // the same histogram in DISTINCT VALUES, estimated: a key is -log2 p of a sampled string, and a string of that
+    // probability is drawn n * 2^-key times in n draws -- a key above log2 n stands for a value of its own, a key
+    // below it for 2^(key - log2 n) of one (16-bit fixed point).  Keys that are no such scores only make the bins
+    // uneven: a bin that outgrows its table refuses the build.
+    __shared__ u32 histd[CELLS];
     __syncthreads();
-    for (u32 i = tid; i < (u32)CELLS; i += SNIFF_THREADS) hist[i] = 0;
+    for (u32 i = tid; i < (u32)CELLS; i += SNIFF_THREADS) {
+        hist[i] = 0;
+        histd[i] = 0;
+    }
     __syncthreads();
     {
         const BinMap cm = bin_map(s_lo, s_hi, nullptr);
+        const double ln = log2((double)n);
 #pragma unroll
         for (int q = 0; q < PER; ++q)
-            if (have[q] && k[q] < F64_INF && !over[q]) atomicAdd(&hist[cell_of(cm, k[q])], 1u);
+            if (have[q] && k[q] < F64_INF && !over[q]) {
+                const u32 cell = cell_of(cm, k[q]);
+                atomicAdd(&hist[cell], 1u);
+                if (w.eq_distinct > 0.0) {
+                    const double v = __longlong_as_double((long long)k[q]);
+                    const double share = v >= ln ? 1.0 : exp2(v - ln);
+                    atomicAdd(&histd[cell], (u32)(share * 65536.0 + 0.5));
+                }
+            }
     }
     __syncthreads();
     {
         const u32 c4[4] = {hist[4 * tid], hist[4 * tid + 1], hist[4 * tid + 2], hist[4 * tid + 3]};
-        const u32 mine = c4[0] + c4[1] + c4[2] + c4[3];
-        u32 inc = mine;
+        const u32 d4[4] = {histd[4 * tid], histd[4 * tid + 1], histd[4 * tid + 2], histd[4 * tid + 3]};
+        const u32 mine = c4[0] + c4[1] + c4[2] + c4[3], mined = d4[0] + d4[1] + d4[2] + d4[3];
+        u32 inc = mine, incd = mined;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const u32 t = __shfl_up(inc, o);
-            if (lane >= o) inc += t;
+            const u32 t = __shfl_up(inc, o), td = __shfl_up(incd, o);
+            if (lane >= o) {
+                inc += t;
+                incd += td;
+            }
         }
-        if (lane == 63) wtot16[wid] = inc;
+        if (lane == 63) {
+            wtot16[wid] = inc;
+            wtotd[wid] = incd;
+        }
         __syncthreads();
-        u32 off = 0, total = 0;
+        u32 off = 0, total = 0, offd = 0, totald = 0;
         for (int i = 0; i < SNIFF_THREADS / 64; ++i) {
-            if (i < wid) off += wtot16[i];
+            if (i < wid) {
+                off += wtot16[i];
+                offd += wtotd[i];
+            }
             total += wtot16[i];
+            totald += wtotd[i];
         }
         u32 before = off + inc - mine;  // sample keys in the cells before this thread's four
+        u32 befored = offd + incd - mined;  // ... and distinct sample values
         // a cell's bin: a quarter from the share of the sample below it, three quarters from the cell's own place in
         // the range.  Equal-width bins hold up to 43,000 of the headline step's 1.96e6 tail keys (the mean is 1900)
         // and at most 921 distinct values; bins of equal numbers of keys grow wide where keys are few but all
@@ -474,12 +507,16 @@ __global__ void __launch_bounds__(SNIFF_THREADS) k_rl_sniff(RWs w) {
         for (int j = 0; j < 4; ++j) {
             const u32 c = 4 * tid + j;
             const double lin = (double)c / (double)CELLS;
-            const double f = total ? 0.25 * ((double)before / (double)total) + 0.75 * lin : lin;
+            double f = total ? w.eq_share * ((double)before / (double)total) + (1.0 - w.eq_share) * lin : lin;
+            if (w.eq_distinct > 0.0 && total && totald)
+                f = w.eq_share * ((double)before / (double)total) + w.eq_distinct * ((double)befored / (double)totald) +
+                    (1.0 - w.eq_share - w.eq_distinct) * lin;
             u32 bin = (u32)(f * (double)w.P);
             if (bin >= w.P) bin = w.P - 1;
             slut[c] = (unsigned short)bin;
             w.lut[c] = (unsigned short)bin;
             before += c4[j];
+            befored += d4[j];
         }
     }
     __syncthreads();
@@ -504,7 +541,7 @@ __global__ void __launch_bounds__(SNIFF_THREADS) k_rl_sniff(RWs w) {
 }
 
 // ---- strip: count the copies of heavy values, order the rest by bin ------------------------------------------
-__global__ void __launch_bounds__(WG, 4) k_rl_strip(RWs w) {  // (4 waves per SIMD = two workgroups a CU)
+__device__ __forceinline__ void rl_strip_body(const RWs &w) {
     static_assert(HSET == 2048, "strip_hash yields 11 bits");
     static_assert(TBUF == TILE && TBUF == ITEMS * WG, "a batch is flushed by the whole workgroup, ITEMS keys a lane");
     static_assert(P_MAX == 2 * WG, "the scan of the bins' counts takes two bins a thread");
@@ -792,7 +829,7 @@ __device__ __forceinline__ T bins_incl_scan(T v, T *wt, T &total) {
     return off + inc;
 }
 
-__global__ void __launch_bounds__(BW) k_rl_bins(RWs w) {
+__device__ __forceinline__ void rl_bins_body(const RWs &w) {
     static_assert(SUB % BW == 0 && OVS % BW == 0 && SEG_MAX % BW == 0, "whole rounds of the workgroup");
     static_assert(MAIN_CAP + OVCAP <= CAPD, "a bin's runs fit its place in the workspace");
     static_assert(SUB + OVCAP < 65536, "entry ids are 16 bits");
@@ -1101,7 +1138,7 @@ __global__ void __launch_bounds__(BW) k_rl_bins(RWs w) {
 }
 
 // ---- prefix over the bins, runs to their final places ---------------------------------------------------------
-__global__ void __launch_bounds__(WG) k_rl_final(RWs w) {
+__device__ __forceinline__ void rl_final_body(const RWs &w) {
     __shared__ u32 wt32[NWAVE];
     __shared__ u64 wt64[NWAVE];
     __shared__ double wtf[NWAVE];
@@ -1167,6 +1204,429 @@ __global__ void __launch_bounds__(WG) k_rl_final(RWs w) {
         w.out_vals[dtot] = EMPTY;
         w.out_ccum[dtot] = ctot + allones;
         w.out_wcum[dtot] = __longlong_as_double(0x7FF8000000000000ll);  // (as a double the key is a NaN: so is its weight)
+    }
+}
+
+
+// the four steps as kernels: of one build (mc_rank_runs_build up to 2^26 keys), and of the BIG_G builds a large one
+// is made of, side by side (blockIdx.y picks the build; its description lies in memory, written by k_big_setup)
+__global__ void __launch_bounds__(SNIFF_THREADS) k_rl_sniff(RWs w) { rl_sniff_body(w); }
+__global__ void __launch_bounds__(WG, 4) k_rl_strip(RWs w) { rl_strip_body(w); }  // (4 waves per SIMD = two workgroups a CU)
+__global__ void __launch_bounds__(BW) k_rl_bins(RWs w) { rl_bins_body(w); }
+__global__ void __launch_bounds__(WG) k_rl_final(RWs w) { rl_final_body(w); }
+__global__ void __launch_bounds__(SNIFF_THREADS) k_rlg_sniff(const RWs *pw) {
+    const RWs w = pw[blockIdx.y];
+    if (w.n) rl_sniff_body(w);
+}
+__global__ void __launch_bounds__(WG, 4) k_rlg_strip(const RWs *pw) {
+    const RWs w = pw[blockIdx.y];
+    if (w.n) rl_strip_body(w);
+}
+__global__ void __launch_bounds__(BW) k_rlg_bins(const RWs *pw) {
+    const RWs w = pw[blockIdx.y];
+    if (w.n) rl_bins_body(w);
+}
+__global__ void __launch_bounds__(WG) k_rlg_final(const RWs *pw) {
+    const RWs w = pw[blockIdx.y];
+    if (w.n) rl_final_body(w);
+}
+
+
+// ======== builds of more than 2^26 keys ==========================================================================
+// The same index from two levels of the same steps.  Level 1 (k_rl_sniff over all keys, then k_big_strip) reads every
+// key ONCE: copies of the heavy values the sample found are counted in LDS as k_rl_strip counts them; every other key
+// goes to one of BIG_G value-range GROUPS (the sample's tail in equal shares: the look-up table at equal depth) --
+// buffered in LDS, ordered by group, and written behind the group's cursor, one atomic add per group and batch.  A
+// group is then an input like any other, of a few million keys in one value range: k_big_setup writes the
+// description of each group's build into memory and the four steps run for all groups side by side (k_rlg_*: the
+// bodies above, blockIdx.y = group; a group's own sample finds the values that are frequent INSIDE it -- the second
+// tier, ~1e-5 of all keys each -- and its own look-up table spreads ITS range over its bins).  k_big_join puts the
+// groups' runs one after the other, the level-1 heavy values in between where they belong, and adds the bases.
+// Nothing waits for anything inside a kernel.  A group that outgrows its share of the workspace (keys whose tail is
+// most of the input, or falls into few groups) or a bin that outgrows its table fails the build, loudly, as above.
+// Where this stands (scripts/runs_big_check.py, profiles/r03_*_runs_two_level.txt): correct against mc_rank_build at
+// 7e7 and 2e8 keys of both benchmark models (every count equal, positions within 6e-15), 2.56 against 3.12 ms at 2e8
+// keys of the v2 model but 1.75 against 1.49 ms at 7e7; at 1.25e9 keys of the v2 model the last groups hold 0.8 - 1e6
+// keys that are ALL distinct -- more than a group's 256 tables take -- and the build refuses after 11 ms (k_big_strip
+// 5.6 ms: its tail is 40 % of the keys with the 16384-key sample's list; k_rlg_strip 2.2, k_rlg_bins 2.7).  The host
+// classes therefore keep mc_rank_build beyond 2^26 keys (mc_rank_runs_max_keys); callers that pass their own
+// RunsBuffers get this build.
+constexpr int BIG_G = 64;      // groups
+constexpr int BIG_P = 256;     // bins of a group's own build
+constexpr u64 BIG_MAX_N = 0xFFFFFFFFull;
+enum { ERR_GROUP = 64u };
+
+struct BigCtl {
+    u32 err, pad;
+    u64 gcur[BIG_G];  // keys written to each group
+};
+
+struct BWs {
+    RWs top;          // level 1: ctl, heavy, hcnt, in, hbin, lut, cell0; n; P = BIG_G
+    RWs templ;        // a group's build, group 0's pointers (group g's: + g * slice bytes), fields for `cap` keys
+    size_t slice;
+    BigCtl *bctl;
+    RWs *problems;    // [BIG_G]
+    u64 *gkeys;       // [BIG_G][cap]
+    u64 n;            // all keys
+    u64 cap;          // keys a group takes
+    u32 region;       // keys per workgroup of k_big_strip (whole tiles)
+    u64 *g_vals, *g_ccum;  // the groups' own indexes: [BIG_G][gcap]
+    double *g_wcum;
+    u64 *g_info;      // [BIG_G][8]
+    u64 gcap;
+    u64 *out_vals, *out_ccum;
+    double *out_wcum;
+    u64 *out_info;
+    u64 out_cap;
+};
+
+__global__ void __launch_bounds__(64) k_big_clear(BWs bw) {
+    if (threadIdx.x == 0) bw.bctl->err = 0;
+    if (threadIdx.x < BIG_G) bw.bctl->gcur[threadIdx.x] = 0;
+}
+
+__global__ void __launch_bounds__(WG, 4) k_big_strip(BWs bw) {
+    static_assert(BIG_G == 64, "one wave scans the groups' counts");
+    const RWs &w = bw.top;
+    __shared__ u64 hk[HSET + 1];
+    __shared__ u32 hs[HSET + 1];
+    __shared__ u32 hi[HSET];
+    __shared__ u64 tb[TBUF];
+    __shared__ unsigned short slut[CELLS];
+    __shared__ u32 gh[BIG_G], goff[BIG_G + 1];
+    __shared__ u64 gbase[BIG_G];
+    __shared__ u32 tfill;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const u32 H = w.ctl->n_heavy <= (u32)H_MAX ? w.ctl->n_heavy : 0u;
+    const BinMap bm = bin_map(w.ctl->map_lo, w.ctl->map_hi, slut);
+    for (u32 i = tid; i <= (u32)HSET; i += WG) {
+        hk[i] = EMPTY;
+        hs[i] = 0;
+    }
+    for (u32 i = tid; i < (u32)CELLS / 2; i += WG) ((u32 *)slut)[i] = ((const u32 *)w.lut)[i];
+    __syncthreads();
+    for (u32 i = tid; i < H; i += WG) {
+        const u64 v = w.heavy[i];
+        if (v == EMPTY) continue;
+        u32 s = strip_hash(v);
+        for (;;) {
+            const u64 old = atomicCAS(&hk[s], EMPTY, v);
+            if (old == EMPTY) {
+                hi[s] = i;
+                break;
+            }
+            if (old == v) break;
+            s = (s + 1) & (HSET - 1);
+        }
+    }
+    __syncthreads();
+    const u64 lt = (1ull << lane) - 1ull;
+
+    // one batch: the first m keys of tb, ordered by group, each group's share written behind its cursor
+    auto flush = [&](u32 m) {
+        if (tid < BIG_G) gh[tid] = 0;
+        __syncthreads();
+        u64 key[ITEMS];
+        u32 grp[ITEMS], rk[ITEMS];
+#pragma unroll
+        for (int q = 0; q < ITEMS; ++q) {
+            const u32 i = q * WG + tid;
+            key[q] = i < m ? tb[i] : 0ull;
+            grp[q] = bin_of(bm, key[q]);
+            if (grp[q] >= (u32)BIG_G) grp[q] = BIG_G - 1;
+        }
+#pragma unroll
+        for (int q = 0; q < ITEMS; ++q) {
+            const u32 i = q * WG + tid;
+            rk[q] = i < m ? atomicAdd(&gh[grp[q]], 1u) : 0u;
+        }
+        __syncthreads();
+        if (tid < BIG_G) {
+            const u32 c = gh[tid];
+            u32 inc = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const u32 t = __shfl_up(inc, o);
+                if (lane >= o) inc += t;
+            }
+            goff[tid] = inc - c;
+            if (tid == BIG_G - 1) goff[BIG_G] = inc;
+            gbase[tid] = c ? atomicAdd(&bw.bctl->gcur[tid], (u64)c) : 0ull;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < ITEMS; ++q) {
+            const u32 i = q * WG + tid;
+            if (i < m) {
+                const u32 at = goff[grp[q]] + rk[q];
+                if (at < m) tb[at] = key[q]; else atomicOr(&bw.bctl->err, ERR_RANGE);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < ITEMS; ++q) {  // consecutive lanes on consecutive addresses inside a group's share
+            const u32 i = q * WG + tid;
+            if (i < m) {
+                const u64 k2 = tb[i];
+                u32 g = bin_of(bm, k2);
+                if (g >= (u32)BIG_G) g = BIG_G - 1;
+                const u64 at = gbase[g] + (i - goff[g]);
+                if (at < bw.cap) bw.gkeys[(u64)g * bw.cap + at] = k2; else atomicOr(&bw.bctl->err, ERR_GROUP);
+            }
+        }
+        __syncthreads();
+    };
+
+    const u64 n = bw.n;
+    const u64 lo = (u64)blockIdx.x * bw.region;
+    if (lo < n) {
+        const u32 rn = (u32)(n - lo < (u64)bw.region ? n - lo : (u64)bw.region);
+        if (tid == 0) tfill = 0;
+        __syncthreads();
+        u64 k[ITEMS], nk[ITEMS];
+#pragma unroll
+        for (int q = 0; q < ITEMS; ++q) {
+            const u32 j = q * WG + tid;
+            nk[q] = w.in[lo + (j < rn ? j : rn - 1)];
+        }
+        for (u32 c0 = 0; c0 < rn; c0 += TILE) {
+#pragma unroll
+            for (int q = 0; q < ITEMS; ++q) k[q] = nk[q];
+            if (c0 + TILE < rn) {
+#pragma unroll
+                for (int q = 0; q < ITEMS; ++q) {
+                    const u32 j = c0 + TILE + q * WG + tid;
+                    nk[q] = w.in[lo + (j < rn ? j : rn - 1)];
+                }
+            }
+            u64 tmask[ITEMS];
+            u32 total = 0;
+            {
+                u32 sl[ITEMS];
+                u64 a[ITEMS], b[ITEMS];
+#pragma unroll
+                for (int q = 0; q < ITEMS; ++q) {
+                    sl[q] = strip_hash(k[q]);
+                    a[q] = hk[sl[q]];
+                    b[q] = hk[sl[q] + 1];
+                }
+#pragma unroll
+                for (int q = 0; q < ITEMS; ++q) {
+                    const bool valid = c0 + q * WG + tid < rn;
+                    const bool real = valid && k[q] != EMPTY;  // (a key of all ones matches the table's empty marker: never heavy)
+                    const bool hit_a = real && a[q] == k[q];
+                    const bool hit_b = real && !hit_a && a[q] != EMPTY && b[q] == k[q];
+                    const bool walk = real && !hit_a && !hit_b && a[q] != EMPTY && (b[q] != EMPTY || sl[q] + 1 == (u32)HSET);
+                    bool heavy = hit_a || hit_b;
+                    u32 slot = sl[q] + (hit_b ? 1u : 0u);
+                    if (__ballot(walk)) {  // (rare)
+                        if (walk) {
+                            u32 t = sl[q] + 1 == (u32)HSET ? 0u : (sl[q] + 2 == (u32)HSET ? 0u : sl[q] + 2);
+                            for (;;) {
+                                const u64 v = hk[t];
+                                if (v == k[q]) {
+                                    heavy = true;
+                                    slot = t;
+                                    break;
+                                }
+                                if (v == EMPTY) break;
+                                t = t + 1 == (u32)HSET ? 0u : t + 1;
+                            }
+                        }
+                    }
+                    if (heavy) atomicAdd(&hs[slot], 1u);
+                    tmask[q] = __ballot(valid && !heavy);
+                    total += (u32)__popcll(tmask[q]);
+                }
+            }
+            u32 base = 0;
+            if (total) {
+                if (lane == 0) base = atomicAdd(&tfill, total);
+                base = __builtin_amdgcn_readfirstlane(base);
+            }
+            u32 pos[ITEMS];
+#pragma unroll
+            for (int q = 0; q < ITEMS; ++q) {
+                const bool tail = (tmask[q] >> lane) & 1ull;
+                pos[q] = tail ? base + (u32)__popcll(tmask[q] & lt) : 0xFFFFFFFFu;
+                if (tail && pos[q] < (u32)TBUF) tb[pos[q]] = k[q];
+                base += (u32)__popcll(tmask[q]);
+            }
+            __syncthreads();
+            if (tfill >= (u32)TBUF) {  // (uniform) a full batch; what did not fit opens the next one
+                flush((u32)TBUF);
+#pragma unroll
+                for (int q = 0; q < ITEMS; ++q)
+                    if (pos[q] != 0xFFFFFFFFu && pos[q] >= (u32)TBUF) tb[pos[q] - (u32)TBUF] = k[q];
+                if (tid == 0) tfill -= (u32)TBUF;
+                __syncthreads();
+            }
+        }
+        const u32 m = tfill;
+        __syncthreads();
+        if (m) flush(m);
+    }
+    __syncthreads();
+    u32 *hc = (u32 *)tb;
+    for (u32 i = tid; i < H; i += WG) hc[i] = 0;
+    __syncthreads();
+    for (u32 i = tid; i < (u32)HSET; i += WG)
+        if (hk[i] != EMPTY && hs[i]) hc[hi[i]] = hs[i];
+    __syncthreads();
+    for (u32 i = tid; i < H; i += WG)
+        if (hc[i]) atomicAdd(&w.hcnt[i], hc[i]);
+}
+
+template <typename T>
+__device__ __forceinline__ void move_on(T *&p, size_t by) { p = (T *)((char *)p + by); }
+
+// the description of every group's own build: group 0's with every pointer moved on by g slices, the keys the
+// group received, its regions
+__global__ void __launch_bounds__(64) k_big_setup(BWs bw) {
+    const u32 g = threadIdx.x;
+    if (g >= (u32)BIG_G) return;
+    const u64 ng = bw.bctl->gcur[g];
+    const bool fits = ng <= bw.cap;
+    if (!fits) atomicOr(&bw.bctl->err, ERR_GROUP);
+    RWs p = bw.templ;
+    const size_t by = (size_t)g * bw.slice;
+    move_on(p.ctl, by); move_on(p.heavy, by); move_on(p.hcnt, by); move_on(p.tail, by); move_on(p.nbatch, by);
+    move_on(p.rmax, by); move_on(p.hbin, by); move_on(p.lut, by); move_on(p.cell0, by); move_on(p.start, by);
+    move_on(p.rval, by); move_on(p.rccum, by); move_on(p.rwcum, by); move_on(p.bin_d, by); move_on(p.bin_c, by);
+    move_on(p.bin_w, by);
+    p.in = bw.gkeys + (u64)g * bw.cap;
+    p.n = fits ? (u32)ng : 0u;
+    p.regions = p.n ? (p.n + p.region - 1) / p.region : 0u;
+    p.out_vals = bw.g_vals + (u64)g * bw.gcap;
+    p.out_ccum = bw.g_ccum + (u64)g * bw.gcap;
+    p.out_wcum = bw.g_wcum + (u64)g * bw.gcap;
+    p.out_info = bw.g_info + (u64)g * 8;
+    p.out_cap = bw.gcap;
+    bw.problems[g] = p;
+    if (!p.n)
+        for (int i = 0; i < 8; ++i) p.out_info[i] = 0;  // (an index of no runs; k_rlg_* leave the group alone)
+}
+
+// the groups' runs in order, the level-1 heavy values where they belong, the running counts and weights on top of
+// what lies before.  Every workgroup adds up the same bases in the same order.
+__global__ void __launch_bounds__(256) k_big_join(BWs bw) {
+    const RWs &w = bw.top;
+    __shared__ u64 hv[H_MAX];
+    __shared__ u64 hcp[H_MAX + 1];
+    __shared__ double hwp[H_MAX + 1];
+    __shared__ u64 dbase[BIG_G + 1], cbase[BIG_G + 1];
+    __shared__ double wbase[BIG_G + 1];
+    __shared__ u32 s_err;
+    __shared__ u64 s_heavy2, s_tail2;
+    const int tid = threadIdx.x;
+    const u32 H = w.ctl->n_heavy <= (u32)H_MAX ? w.ctl->n_heavy : 0u;
+    for (u32 i = tid; i < H; i += 256) hv[i] = w.heavy[i];
+    if (tid == 0) {
+        u32 e = bw.bctl->err | w.ctl->err;
+        u64 d = 0, c = 0, h2 = 0, t2 = 0;
+        double ws = 0.0;
+        for (int g = 0; g < BIG_G; ++g) {
+            const u64 *gi = bw.g_info + (u64)g * 8;
+            dbase[g] = d;
+            cbase[g] = c;
+            wbase[g] = ws;
+            const u64 dg = gi[0] <= bw.gcap ? gi[0] : 0ull;
+            e |= (u32)gi[1];
+            if (gi[2] != bw.bctl->gcur[g]) e |= ERR_COUNT;  // (every key a group received is in its index)
+            h2 += gi[3];
+            t2 += gi[4];
+            if (dg) {
+                c += bw.g_ccum[(u64)g * bw.gcap + dg - 1];
+                ws += bw.g_wcum[(u64)g * bw.gcap + dg - 1];
+            }
+            d += dg;
+        }
+        dbase[BIG_G] = d;
+        cbase[BIG_G] = c;
+        wbase[BIG_G] = ws;
+        u64 hc = 0;
+        double hw = 0.0;
+        hcp[0] = 0;
+        hwp[0] = 0.0;
+        for (u32 i = 0; i < H; ++i) {
+            const u64 cnt = w.hcnt[i];
+            hc += cnt;
+            hw += (double)cnt * exp2(__longlong_as_double((long long)w.heavy[i]) - w.logn);
+            hcp[i + 1] = hc;
+            hwp[i + 1] = hw;
+        }
+        if (!e && c + hc != bw.n) e |= ERR_COUNT;
+        if (!e && d + H > bw.out_cap) e |= ERR_RANGE;
+        s_err = e;
+        s_heavy2 = h2;
+        s_tail2 = t2;
+    }
+    __syncthreads();
+    const u32 err = s_err;
+    const u64 D2 = dbase[BIG_G];
+    if (blockIdx.x == 0 && tid == 0) {
+        bw.out_info[0] = err ? 0ull : D2 + H;
+        bw.out_info[1] = err;
+        bw.out_info[2] = cbase[BIG_G] + hcp[H];
+        bw.out_info[3] = H + s_heavy2;
+        bw.out_info[4] = s_tail2;
+        bw.out_info[5] = 0;
+        // (what refused: a group's keys against its share, or the first refusing group's own words)
+        bw.out_info[6] = 0;
+        bw.out_info[7] = 0;
+        if (err & ERR_GROUP) {
+            u64 most = 0;
+            for (int g = 0; g < BIG_G; ++g) most = bw.bctl->gcur[g] > most ? bw.bctl->gcur[g] : most;
+            bw.out_info[6] = most;
+            bw.out_info[7] = bw.cap;
+        } else if (err & ERR_BIN) {
+            for (int g = 0; g < BIG_G; ++g)
+                if (bw.g_info[(u64)g * 8 + 1] & ERR_BIN) {
+                    bw.out_info[6] = bw.g_info[(u64)g * 8 + 6] | ((u64)g << 56);
+                    bw.out_info[7] = bw.g_info[(u64)g * 8 + 7];
+                    break;
+                }
+        }
+    }
+    if (err) return;
+    const u64 stride = (u64)gridDim.x * 256u;
+    for (u64 j = (u64)blockIdx.x * 256u + tid; j < D2; j += stride) {  // a run of a group
+        u32 g = 0;
+        for (u32 st = BIG_G / 2; st; st >>= 1)
+            if (dbase[g + st] <= j) g += st;
+        const u64 l = j - dbase[g], at = (u64)g * bw.gcap + l;
+        const u64 v = bw.g_vals[at];
+        u32 lo = 0, hi = H;  // level-1 heavy values below v
+        while (lo < hi) {
+            const u32 mid = (lo + hi) >> 1;
+            if (hv[mid] < v) lo = mid + 1; else hi = mid;
+        }
+        const u64 o = j + lo;
+        bw.out_vals[o] = v;
+        bw.out_ccum[o] = cbase[g] + bw.g_ccum[at] + hcp[lo];
+        bw.out_wcum[o] = (wbase[g] + bw.g_wcum[at]) + hwp[lo];
+    }
+    if (blockIdx.x == 0) {
+        const BinMap bm = bin_map(w.ctl->map_lo, w.ctl->map_hi, w.lut);
+        for (u32 i = tid; i < H; i += 256) {  // a level-1 heavy value: behind the runs of its group that lie below it
+            const u64 v = hv[i];
+            u32 g = bin_of(bm, v);
+            if (g >= (u32)BIG_G) g = BIG_G - 1;
+            const u64 dg = dbase[g + 1] - dbase[g];
+            const u64 *gv = bw.g_vals + (u64)g * bw.gcap;
+            u64 lo = 0, hi = dg;
+            while (lo < hi) {
+                const u64 mid = (lo + hi) >> 1;
+                if (gv[mid] < v) lo = mid + 1; else hi = mid;
+            }
+            const u64 o = dbase[g] + lo + i;
+            const u64 cb = cbase[g] + (lo ? bw.g_ccum[(u64)g * bw.gcap + lo - 1] : 0ull);
+            const double wb = lo ? wbase[g] + bw.g_wcum[(u64)g * bw.gcap + lo - 1] : wbase[g];
+            bw.out_vals[o] = v;
+            bw.out_ccum[o] = cb + hcp[i + 1];
+            bw.out_wcum[o] = wb + hwp[i + 1];
+        }
     }
 }
 
@@ -1239,7 +1699,7 @@ struct RLayout {
     u32 region, regions, nb, P;
 };
 
-RLayout layout_for(u64 n) {
+RLayout layout_for(u64 n, u32 force_P = 0) {
     RLayout L;
     // keys per strip region: whole tiles, as few as give every k_rl_strip workgroup the GPU holds at once one region
     const u64 tiles = (n + TILE - 1) / TILE;
@@ -1249,7 +1709,7 @@ RLayout layout_for(u64 n) {
     if (L.regions == 0) L.regions = 1;
     L.nb = L.region / TBUF;
     // bins: a bin costs a workgroup of k_rl_bins whatever it holds, and a bin may hold CAPD distinct values
-    L.P = n >= (1ull << 21) ? 1024u : n >= (1ull << 17) ? 256u : 64u;
+    L.P = force_P ? force_P : n >= (1ull << 21) ? 1024u : n >= (1ull << 17) ? 256u : 64u;
     size_t p = 0;
     L.ctl = p; p += align256(sizeof(RCtl));
     L.heavy = p; p += align256(H_MAX * sizeof(u64));
@@ -1271,14 +1731,144 @@ RLayout layout_for(u64 n) {
     return L;
 }
 
+struct BLayout {
+    size_t ctl, heavy, hcnt, hbin, lut, cell0, bctl, problems, g_info, g_vals, g_ccum, g_wcum, gkeys, slices, slice, end;
+    u64 cap, gcap;
+    u32 region, regions;
+    RLayout grp;
+};
+
+BLayout big_layout(u64 n) {
+    BLayout B;
+    const u64 tiles = (n + TILE - 1) / TILE;
+    const u64 per = (tiles + STRIP_SLOTS - 1) / STRIP_SLOTS;
+    B.region = (u32)(per * TILE);
+    B.regions = (u32)((n + B.region - 1) / B.region);
+    // a group takes 1.25 n / BIG_G keys (whole tiles): the tail of keys that suit the index is under half of them and
+    // the groups share it half by keys, half by distinct values; whatever needs more is refused (ERR_GROUP) and
+    // sorted by mc_rank_build
+    B.cap = (((n + n / 4) / BIG_G + TILE - 1) / TILE + 1) * TILE;
+    B.gcap = (u64)BIG_P * CAPD + 1;
+    B.grp = layout_for(B.cap, BIG_P);
+    B.slice = align256(B.grp.end);
+    size_t p = 0;
+    B.ctl = p; p += align256(sizeof(RCtl));
+    B.heavy = p; p += align256(H_MAX * sizeof(u64));
+    B.hcnt = p; p += align256(H_MAX * sizeof(u32));
+    B.hbin = p; p += align256((P_MAX + 1) * sizeof(u32));
+    B.lut = p; p += align256(CELLS * sizeof(unsigned short));
+    B.cell0 = p; p += align256((P_MAX + 1) * sizeof(unsigned short));
+    B.bctl = p; p += align256(sizeof(BigCtl));
+    B.problems = p; p += align256(BIG_G * sizeof(RWs));
+    B.g_info = p; p += align256(BIG_G * 8 * sizeof(u64));
+    B.g_vals = p; p += align256((size_t)BIG_G * B.gcap * sizeof(u64));
+    B.g_ccum = p; p += align256((size_t)BIG_G * B.gcap * sizeof(u64));
+    B.g_wcum = p; p += align256((size_t)BIG_G * B.gcap * sizeof(double));
+    B.gkeys = p; p += align256((size_t)BIG_G * B.cap * sizeof(u64));
+    B.slices = p; p += (size_t)BIG_G * B.slice;
+    B.end = p;
+    return B;
+}
+
+int build_big(const double *keys_in, uint64_t n, uint64_t n_global, double *vals, uint64_t *cum_count, double *cum_pos,
+              uint64_t capacity, uint64_t *info, void *workspace, size_t workspace_bytes, hipStream_t s) {
+    const BLayout B = big_layout(n);
+    if (workspace_bytes < B.end) {
+        mc_set_error("mc_rank_runs_build: workspace of %zu bytes, need %zu", workspace_bytes, B.end);
+        return MC_ERR_WORKSPACE;
+    }
+    if (capacity < mc_rank_runs_capacity(n)) {
+        mc_set_error("mc_rank_runs_build: output arrays of %llu entries, need %llu (mc_rank_runs_capacity)",
+                     (unsigned long long)capacity, (unsigned long long)mc_rank_runs_capacity(n));
+        return MC_ERR_ARG;
+    }
+    char *base = (char *)workspace;
+    BWs bw;
+    std::memset(&bw, 0, sizeof bw);
+    const double logn = std::log2((double)n_global);
+    RWs &t = bw.top;
+    t.ctl = (RCtl *)(base + B.ctl);
+    t.heavy = (u64 *)(base + B.heavy);
+    t.hcnt = (u32 *)(base + B.hcnt);
+    t.hbin = (u32 *)(base + B.hbin);
+    t.lut = (unsigned short *)(base + B.lut);
+    t.cell0 = (unsigned short *)(base + B.cell0);
+    t.in = (const u64 *)keys_in;
+    t.n = (u32)n;
+    t.P = BIG_G;
+    t.logn = logn;
+    t.eq_share = 0.5;      // groups: half by keys (a group's share of the workspace), half by distinct values (its bins' tables)
+    t.eq_distinct = 0.5;
+    char *g0 = base + B.slices;
+    const RLayout &L = B.grp;
+    RWs &w = bw.templ;
+    w.ctl = (RCtl *)(g0 + L.ctl);
+    w.heavy = (u64 *)(g0 + L.heavy);
+    w.hcnt = (u32 *)(g0 + L.hcnt);
+    w.tail = (u64 *)(g0 + L.tail);
+    w.nbatch = (u32 *)(g0 + L.nbatch);
+    w.rmax = (u64 *)(g0 + L.rmax);
+    w.hbin = (u32 *)(g0 + L.hbin);
+    w.lut = (unsigned short *)(g0 + L.lut);
+    w.cell0 = (unsigned short *)(g0 + L.cell0);
+    w.start = (u32 *)(g0 + L.start);
+    w.rval = (u64 *)(g0 + L.rval);
+    w.rccum = (u64 *)(g0 + L.rccum);
+    w.rwcum = (double *)(g0 + L.rwcum);
+    w.bin_d = (u32 *)(g0 + L.bin_d);
+    w.bin_c = (u64 *)(g0 + L.bin_c);
+    w.bin_w = (double *)(g0 + L.bin_w);
+    w.region = L.region;
+    w.nb = L.nb;
+    w.P = L.P;
+    w.logn = logn;
+    w.eq_share = 0.0;      // a group's bins: by distinct values, a quarter by place
+    w.eq_distinct = 0.75;
+    bw.slice = B.slice;
+    bw.bctl = (BigCtl *)(base + B.bctl);
+    bw.problems = (RWs *)(base + B.problems);
+    bw.gkeys = (u64 *)(base + B.gkeys);
+    bw.cap = B.cap;
+    bw.region = B.region;
+    bw.g_vals = (u64 *)(base + B.g_vals);
+    bw.g_ccum = (u64 *)(base + B.g_ccum);
+    bw.g_wcum = (double *)(base + B.g_wcum);
+    bw.g_info = (u64 *)(base + B.g_info);
+    bw.gcap = B.gcap;
+    bw.n = n;
+    bw.out_vals = (u64 *)vals;
+    bw.out_ccum = (u64 *)cum_count;
+    bw.out_wcum = cum_pos;
+    bw.out_info = (u64 *)info;
+    bw.out_cap = capacity;
+    const u32 gx = L.regions < (u32)STRIP_SLOTS ? L.regions : (u32)STRIP_SLOTS;
+    hipLaunchKernelGGL(k_big_clear, dim3(1), dim3(64), 0, s, bw);
+    hipLaunchKernelGGL(k_rl_sniff, dim3(1), dim3(SNIFF_THREADS), 0, s, bw.top);
+    hipLaunchKernelGGL(k_big_strip, dim3(B.regions), dim3(WG), 0, s, bw);
+    hipLaunchKernelGGL(k_big_setup, dim3(1), dim3(64), 0, s, bw);
+    hipLaunchKernelGGL(k_rlg_sniff, dim3(1, BIG_G), dim3(SNIFF_THREADS), 0, s, (const RWs *)bw.problems);
+    hipLaunchKernelGGL(k_rlg_strip, dim3(gx, BIG_G), dim3(WG), 0, s, (const RWs *)bw.problems);
+    hipLaunchKernelGGL(k_rlg_bins, dim3(L.P, BIG_G), dim3(BW), 0, s, (const RWs *)bw.problems);
+    hipLaunchKernelGGL(k_rlg_final, dim3(L.P, BIG_G), dim3(WG), 0, s, (const RWs *)bw.problems);
+    hipLaunchKernelGGL(k_big_join, dim3(2048), dim3(256), 0, s, bw);
+    HIP_TRY(hipGetLastError());
+    return MC_OK;
+}
+
 }  // namespace
 
-extern "C" size_t mc_rank_runs_workspace_bytes(uint64_t n) { return n && n <= RUNS_MAX_N ? layout_for(n).end : 0; }
+extern "C" size_t mc_rank_runs_workspace_bytes(uint64_t n) {
+    if (n == 0 || n > BIG_MAX_N) return 0;
+    return n <= RUNS_MAX_N ? layout_for(n).end : big_layout(n).end;
+}
 
+// (the size up to which the index is the default of the host classes; mc_rank_runs_build itself takes up to 2^32 - 1
+// keys, in two levels beyond this -- measured slower than mc_rank_build at 7e7 keys and refused at 1.25e9, see above)
 extern "C" uint64_t mc_rank_runs_max_keys(void) { return RUNS_MAX_N; }
 
 extern "C" uint64_t mc_rank_runs_capacity(uint64_t n) {
-    if (n == 0 || n > RUNS_MAX_N) return 0;
+    if (n == 0 || n > BIG_MAX_N) return 0;
+    if (n > RUNS_MAX_N) return (u64)BIG_G * big_layout(n).gcap + H_MAX + 1;
     const u64 most = (u64)layout_for(n).P * CAPD;
     return (n < most ? n : most) + 1;
 }
@@ -1299,11 +1889,13 @@ extern "C" int mc_rank_runs_build(const double *keys_in, uint64_t n, uint64_t n_
         mc_set_error("mc_rank_runs_build: bad argument");
         return MC_ERR_ARG;
     }
-    if (n > RUNS_MAX_N) {
+    if (n > BIG_MAX_N) {
         mc_set_error("mc_rank_runs_build: %llu keys, the run index takes at most %llu (use mc_rank_build beyond that)",
-                     (unsigned long long)n, (unsigned long long)RUNS_MAX_N);
+                     (unsigned long long)n, (unsigned long long)BIG_MAX_N);
         return MC_ERR_ARG;
     }
+    if (n > RUNS_MAX_N)
+        return build_big(keys_in, n, n_global, vals, cum_count, cum_pos, capacity, info, workspace, workspace_bytes, s);
     const RLayout L = layout_for(n);
     if (workspace_bytes < L.end) {
         mc_set_error("mc_rank_runs_build: workspace of %zu bytes, need %zu", workspace_bytes, L.end);
@@ -1339,6 +1931,8 @@ extern "C" int mc_rank_runs_build(const double *keys_in, uint64_t n, uint64_t n_
     w.nb = L.nb;
     w.P = L.P;
     w.logn = std::log2((double)n_global);
+    w.eq_share = 0.25;
+    w.eq_distinct = 0.0;
     static const int env_reuse = getenv("MC_SORT_REUSE") ? atoi(getenv("MC_SORT_REUSE")) : 1;
     w.reuse_list = env_reuse ? 1u : 0u;
     w.debug_fail = 0;
@@ -1357,11 +1951,12 @@ extern "C" int mc_rank_runs_build(const double *keys_in, uint64_t n, uint64_t n_
 }
 
 extern "C" int mc_rank_runs_forget(void *workspace, uint64_t n, void *stream) {
-    if (!workspace || n == 0 || n > RUNS_MAX_N) {
-        mc_set_error("mc_rank_runs_forget: null workspace or a key count outside 1 .. 2^26");
+    if (!workspace || n == 0 || n > BIG_MAX_N) {
+        mc_set_error("mc_rank_runs_forget: null workspace or a key count outside 1 .. 2^32 - 1");
         return MC_ERR_ARG;
     }
-    HIP_TRY(hipMemsetAsync((char *)workspace + layout_for(n).ctl, 0, sizeof(RCtl), (hipStream_t)stream));
+    HIP_TRY(hipMemsetAsync((char *)workspace + (n <= RUNS_MAX_N ? layout_for(n).ctl : big_layout(n).ctl), 0, sizeof(RCtl),
+                           (hipStream_t)stream));
     return MC_OK;
 }
 
@@ -1374,9 +1969,10 @@ extern "C" int mc_rank_runs_check(const uint64_t *info, void *stream, uint64_t h
     HIP_TRY(hipMemcpyAsync(local, info, sizeof local, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     if (host_info) for (int i = 0; i < 8; ++i) host_info[i] = local[i];
-    if (local[1] & ERR_BIN) {
+    if (local[1] & (ERR_BIN | ERR_GROUP)) {
         mc_set_error("mc_rank_runs_build: these keys do not suit the run index (a bin of the value range holds more "
-                     "than %d distinct values); queries answer NaN -- build with mc_rank_build instead", CAPD);
+                     "than %d distinct values, or a value-range group of a large build more than its share of the "
+                     "workspace); queries answer NaN -- build with mc_rank_build instead", CAPD);
         return MC_ERR_UNSUITED;
     }
     if (local[1]) {
@@ -1401,6 +1997,26 @@ extern "C" int mc_rank_runs_expand(const double *vals, const uint64_t *cum_count
                        (const u64 *)vals, (const u64 *)cum_count, cum_pos, (const u64 *)info, (u64)n,
                        std::log2((double)n_global), (u64 *)keys_sorted, positions);
     HIP_TRY(hipGetLastError());
+    return MC_OK;
+}
+
+// Development aid (scripts/runs_big_check.py): what the groups of the last large build in `workspace` received and
+// made of it: out[g * 9] = keys, out[g * 9 + 1 .. 8] = the group's own info words.
+extern "C" int mc_rank_runs_debug_groups(const void *workspace, uint64_t n, uint64_t *out, void *stream) {
+    if (!workspace || !out || n <= RUNS_MAX_N || n > BIG_MAX_N) {
+        mc_set_error("mc_rank_runs_debug_groups: bad argument");
+        return MC_ERR_ARG;
+    }
+    const BLayout B = big_layout(n);
+    BigCtl c;
+    uint64_t gi[BIG_G * 8];
+    HIP_TRY(hipMemcpyAsync(&c, (const char *)workspace + B.bctl, sizeof c, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipMemcpyAsync(gi, (const char *)workspace + B.g_info, sizeof gi, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    for (int g = 0; g < BIG_G; ++g) {
+        out[g * 9] = c.gcur[g];
+        for (int i = 0; i < 8; ++i) out[g * 9 + 1 + i] = gi[g * 8 + i];
+    }
     return MC_OK;
 }
 

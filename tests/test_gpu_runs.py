@@ -276,3 +276,43 @@ def test_runs_index_fuzz():
             assert D == uv.numel() and torch.equal(rk.runs.vals[:D].view(torch.int64), uv), (c, kind, n)
             assert torch.equal(rk.runs.cum_count[:D], torch.cumsum(cnt, 0)), (c, kind, n)
     assert kinds["runs"] >= 15 and kinds["sorted"] >= 5, kinds
+
+
+def test_runs_index_in_two_levels_beyond_2_26_keys(model):
+    """mc_rank_runs_build above mc_rank_runs_max_keys() (2^26): level 1 counts the sample's heavy values and hands every
+    other key to one of 64 value-range groups, each group is built like a small input (all side by side), the groups'
+    runs and the level-1 heavy values are joined.  7e7 samples of the headline model against the expanded build:
+    values, cumulative counts, positions, queries, the arrays written back.  Uniform random keys are refused
+    (MC_ERR_UNSUITED, NaN answers, canaries around every buffer intact).  Nothing takes this build by default."""
+    dev = torch.device("cuda")
+    n = 70_000_000
+    assert n > nv.lib.mc_rank_runs_max_keys() and nv.lib.mc_rank_runs_workspace_bytes(n) > 0
+    keys = torch.empty(n, dtype=torch.float64, device=dev)
+    model._dev.sample(n, 12, first_id=5 * n, out=keys)
+    info = check_against_expanded("two levels", keys, n_global=4 * n)
+    assert info[1] == 0 and info[3] > 1000 and 0 < info[4] < n // 2      # heavy values of both levels, a tail under half
+    assert DeviceRank(keys[: 1 << 20]).runs is not None and DeviceRank(keys).runs is None    # (the default: by size)
+    del keys
+    torch.cuda.empty_cache()
+    g = torch.Generator(device="cpu").manual_seed(10)
+    keys = (torch.rand(n, generator=g, dtype=torch.float64) * 60 + 5).to(dev)
+    pad = 4096
+    cap, need = nv.lib.mc_rank_runs_capacity(n), nv.lib.mc_rank_runs_workspace_bytes(n)
+    bufs = {k: torch.full((cap + 2 * pad,), -7.0, dtype=torch.float64, device=dev) for k in ("vals", "cum_pos")}
+    bufs["cum_count"] = torch.full((cap + 2 * pad,), -7, dtype=torch.int64, device=dev)
+    ws_buf = torch.full((need + 2 * pad,), 0x5A, dtype=torch.uint8, device=dev)
+    r = RunsBuffers.__new__(RunsBuffers)
+    r.n, r.tdev, r.capacity = n, keys.device, cap
+    r.vals, r.cum_pos, r.cum_count = (bufs[k][pad:pad + cap] for k in ("vals", "cum_pos", "cum_count"))
+    r.info = torch.zeros(8, dtype=torch.int64, device=dev)
+    r.ws = ws_buf[pad:pad + need]
+    nv.check(nv.lib.mc_rank_runs_forget(_vp(r.ws), n, _stream(dev)))
+    rc, info, _ = build_runs(keys, buffers=r)
+    assert rc == nv.ERR_UNSUITED and info[0] == 0 and info[1] != 0 and b"do not suit" in nv.lib.mc_last_error()
+    assert all(bool((b[:pad] == -7).all()) and bool((b[pad + cap:] == -7).all()) for b in bufs.values())
+    assert bool((ws_buf[:pad] == 0x5A).all()) and bool((ws_buf[pad + need:] == 0x5A).all())
+    x = torch.tensor([10.0, 30.0, 70.0], dtype=torch.float64, device=dev)
+    qp, qc = torch.zeros_like(x), torch.ones(3, dtype=torch.int64, device=dev)
+    nv.check(nv.lib.mc_rank_runs_query(_vp(r.vals), _vp(r.cum_count), _vp(r.cum_pos), _vp(r.info), _vp(x), 3, _vp(qp),
+                                       _vp(qc), _stream(dev)))
+    assert bool(torch.isnan(qp).all()) and bool((qc == 0).all())

@@ -561,7 +561,10 @@ def main():
             "draws_per_sample": draws / N, "indirect_draws_per_draw": indirect / max(draws, 1),
             "threshold_compares_per_draw": probes / max(draws, 1),
             # the longest single launch; HBM traffic from profiles/*pmc_hbm_traffic.json (rocprofv3 --pmc)
-            "roofline": {"bound": "hbm", "kernel": "k_sample", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            # ("hbm" is the roofline the contract prices the kernel against; by its counters the kernel is bound by
+            # vector-ALU issue and the latency of its two dependent gathers an iteration: `valu`)
+            "roofline": {"bound": "hbm", "bound_by_counters": "vector-ALU issue + gather latency (see valu; DESIGN.md 3.1)",
+                         "kernel": "k_sample", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC.get("k_sample"),
                          "traffic_source": TRAFFIC_SOURCE, "valu": VALU,
                          "bytes_per_launch": bytes_per_launch, "kernel_ms": ms["sample"],

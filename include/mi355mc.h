@@ -134,10 +134,16 @@ enum {
     MC_ARR_WORDHASH = 9, /* mc_slot[word_cap]: key = mc_text_hash(symbol text), val = symbol id, pad = length */
     MC_ARR_SYMTEXTOFF = 10, /* uint32[n_sym+1] */
     MC_ARR_SYMTEXT = 11, /* uint32[]: code points */
-    MC_ARR_DENSE = 12    /* mc_payload[n_ctx * n_sym] or empty: for single-character alphabets small enough
+    MC_ARR_DENSE = 12,   /* mc_payload[n_ctx * n_sym] or empty: for single-character alphabets small enough
                           * (n_ctx * n_sym <= 2^22), the transition (row, symbol) with the backoff already
                           * resolved: {ml2p, next, entry} of the longest suffix row that lists the symbol
                           * (backwords_simulator.py:31-38), entry = MC_NONE when there is none */
+    MC_ARR_WORDCK = 13   /* uint64[ck_cap]: the symbol-text map of MC_ARR_WORDHASH once more as a two-choice table for
+                          * look-ups that must end in one round of loads (k_score_words_fast, k_score_bpe_fast): a
+                          * symbol s with text hash h = mc_text_hash(text) and length n sits in slot h & (ck_cap - 1) or
+                          * in slot (((h ^ h >> 29) * 0x9E3779B97F4A7C15) >> 21) & (ck_cap - 1) as
+                          * ((uint32)(h >> 32) ^ n * 0x9E3779B1) << 32 | s; empty slots are all ones.  A tag that
+                          * matches is checked against the symbol's text by the reader.  Empty: no such table */
 };
 int64_t mc_table_array(const mc_table *t, int what, void *dst, size_t cap);
 /* start state, end symbol, root (zero-gram) row, table sizes ... as 16 uint64 (see mc_table_info_idx) */

@@ -22,7 +22,7 @@ KIND_NGRAM, KIND_BACKOFF, KIND_V2, KIND_BPE = 1, 2, 3, 4
 FLAG_KEEP_LEN_ON_RESTART = 1
 FLAG_NO_DENSE = 2
 (ARR_STATE, ARR_DRAW, ARR_CUM, ARR_PAYLOAD, ARR_TRANS, ARR_CTXHASH, ARR_SYMCHARS, ARR_SPAY, ARR_RCUM, ARR_WORDHASH,
- ARR_SYMTEXTOFF, ARR_SYMTEXT, ARR_DENSE) = range(13)
+ ARR_SYMTEXTOFF, ARR_SYMTEXT, ARR_DENSE, ARR_WORDCK) = range(14)
 (INFO_NCTX, INFO_NENT, INFO_NSYM, INFO_START_STATE, INFO_ROOT, INFO_TRANS_CAP, INFO_CTX_CAP, INFO_GUIDE_LEN,
  INFO_DEVICE_BYTES, INFO_MAX_ROW, INFO_KIND, INFO_MULTICHAR, INFO_START_DRAW, INFO_DIRECT_BUCKETS,
  INFO_ONE_BUCKETS, INFO_MULTI_BUCKETS) = range(16)

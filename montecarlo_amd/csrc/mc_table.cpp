@@ -657,6 +657,7 @@ extern "C" int64_t mc_table_array(const mc_table *t, int what, void *dst, size_t
         case MC_ARR_SYMTEXTOFF: src = t->sym_text_off.data(); bytes = t->sym_text_off.size() * sizeof(uint32_t); break;
         case MC_ARR_SYMTEXT: src = t->sym_text.data(); bytes = t->sym_text.size() * sizeof(uint32_t); break;
         case MC_ARR_DENSE: src = t->dense.data(); bytes = t->dense.size() * sizeof(mc_payload); break;
+        case MC_ARR_WORDCK: src = t->wordck.data(); bytes = t->wordck.size() * sizeof(uint64_t); break;
         case MC_ARR_CUM: src = t->cum.data(); bytes = t->cum.size() * sizeof(double); break;
         case MC_ARR_PAYLOAD: src = t->payload.data(); bytes = t->payload.size() * sizeof(mc_payload); break;
         case MC_ARR_TRANS: src = t->trans.data(); bytes = t->trans.size() * sizeof(mc_slot); break;

@@ -164,7 +164,8 @@ class FlatTable:
         dt = {nv.ARR_STATE: STATE_DT, nv.ARR_DRAW: DRAW_DT, nv.ARR_CUM: np.dtype("<f8"),
               nv.ARR_PAYLOAD: PAYLOAD_DT, nv.ARR_TRANS: SLOT_DT, nv.ARR_CTXHASH: SLOT_DT,
               nv.ARR_SYMCHARS: np.dtype("<u4"), nv.ARR_SPAY: DRAW_DT, nv.ARR_RCUM: np.dtype("<f8"),
-              nv.ARR_WORDHASH: SLOT_DT, nv.ARR_SYMTEXTOFF: np.dtype("<u4"), nv.ARR_SYMTEXT: np.dtype("<u4"), nv.ARR_DENSE: PAYLOAD_DT}[what]
+              nv.ARR_WORDHASH: SLOT_DT, nv.ARR_SYMTEXTOFF: np.dtype("<u4"), nv.ARR_SYMTEXT: np.dtype("<u4"), nv.ARR_DENSE: PAYLOAD_DT,
+              nv.ARR_WORDCK: np.dtype("<u8")}[what]
         size = nv.check(nv.lib.mc_table_array(self._h, what, None, 0))
         out = np.empty(size // dt.itemsize, dtype=dt)
         nv.check(nv.lib.mc_table_array(self._h, what, out.ctypes.data_as(C.c_void_p), size))

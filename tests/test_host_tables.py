@@ -559,3 +559,56 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_device():
     rejected(lib.mc_sample_dedup(a, a, 8, 10, 24, a, b, c, big, None), "power of two")
     rejected(lib.mc_model_upload(None, 0, ctypes.byref(ctypes.c_void_p())), "mc_model_upload")
     lib.mc_model_destroy(None)                                                       # a no-op, as free(NULL)
+
+
+def test_two_choice_symbol_table_holds_every_symbol_once(train_tab):
+    """MC_ARR_WORDCK (the symbol-text map as a two-choice table, read by k_score_words_fast / k_score_bpe_fast in one
+    round of loads) against the symbols themselves, by the header's own formulas: every symbol with a text sits in
+    one of its two slots with its tag, in no other slot, and the table holds nothing else; texts that are no symbol
+    find no slot whose tag AND text match (a reader compares the text after a tag hit).  On a sub-word backoff
+    model, a single-character model and a sub-word model of 3000 chunks."""
+    models = [BackWordsMonteCarlo(synth.as_file(train_tab), splitter="\t", threshold=3),
+              BackWordsMonteCarlo(synth.as_file(synth.zipf_corpus(3000, vocab=300, seed=5)), splitter="", threshold=5),
+              BackWordsMonteCarlo(synth.as_file(synth.subword_corpus(20000)), splitter="\t", threshold=10)]
+    M64 = (1 << 64) - 1
+    for m in models:
+        flat = m._flat
+        ck = flat.array(nv.ARR_WORDCK)
+        off, text = flat.array(nv.ARR_SYMTEXTOFF), flat.array(nv.ARR_SYMTEXT)
+        cap = len(ck)
+        assert cap >= 16 and cap & (cap - 1) == 0
+        n_sym = len(off) - 1
+        assert cap >= 4 * sum(1 for s in range(n_sym) if off[s + 1] > off[s])
+
+        def slots(cps):
+            arr = np.ascontiguousarray(cps, dtype=np.uint32)
+            h = int(nv.lib.mc_text_hash(arr.ctypes.data_as(nv.u32p), len(arr)))
+            p2 = ((((h ^ (h >> 29)) * 0x9E3779B97F4A7C15) & M64) >> 21) & (cap - 1)
+            tag = ((h >> 32) ^ ((len(arr) * 0x9E3779B1) & 0xFFFFFFFF)) & 0xFFFFFFFF
+            return h & (cap - 1), p2, tag
+
+        held = {}
+        for s in range(n_sym):
+            cps = text[off[s]:off[s + 1]]
+            if len(cps) == 0:
+                continue
+            p1, p2, tag = slots(cps)
+            want = (tag << 32) | s
+            at = [p for p in {p1, p2} if int(ck[p]) == want]
+            assert len(at) == 1, (s, p1, p2)
+            held[at[0]] = want
+        occupied = {i: int(v) for i, v in enumerate(ck.tolist()) if int(v) != M64}
+        assert occupied == held
+        # texts that are no symbols: a tag hit (if any) names a symbol of another text
+        rng = np.random.default_rng(2)
+        known = {tuple(text[off[s]:off[s + 1]].tolist()) for s in range(n_sym)}
+        for _ in range(3000):
+            cps = tuple(int(c) for c in rng.integers(33, 126, size=int(rng.integers(1, 7))))
+            if cps in known:
+                continue
+            p1, p2, tag = slots(cps)
+            for p in (p1, p2):
+                v = int(ck[p])
+                if v != M64 and (v >> 32) == tag:
+                    s = v & 0xFFFFFFFF
+                    assert tuple(text[off[s]:off[s + 1]].tolist()) != cps

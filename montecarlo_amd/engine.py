@@ -223,9 +223,23 @@ class RunsBuffers:
             nv.check(nv.lib.mc_rank_runs_forget(_vp(self.ws), self.n, C.c_void_p(torch.cuda.current_stream(self.tdev).cuda_stream)))
 
 
+# The size from which this process has seen the run index refuse its keys (a refused build costs its 0.1-1 ms and
+# the expanded build after it): later default builds of that many keys or more take mc_rank_build straight away.
+# Models differ -- 1e7 samples of the headline model hold 170,000 distinct values and suit the index up to 1e7
+# keys, those of the v2 6-gram model up to 4e6, those of a sub-word model a million values and do not
+# (scripts/runs_sweep.py, profiles/r03_d_runs_sweep.txt); nothing but a build tells.  `forget_rank_choices()` starts over.
+_PREFER_SORTED_FROM = [None]
+
+
+def forget_rank_choices():
+    _PREFER_SORTED_FROM[0] = None
+
+
 def runs_index_wanted(n: int) -> bool:
     """The run-length index is the default wherever it applies; MC_RANK_INDEX=sorted keeps the expanded arrays."""
     import os
+    if _PREFER_SORTED_FROM[0] is not None and n >= _PREFER_SORTED_FROM[0]:
+        return False
     return 0 < n <= int(nv.lib.mc_rank_runs_max_keys()) and os.environ.get("MC_RANK_INDEX", "runs") != "sorted"
 
 
@@ -236,7 +250,8 @@ class DeviceRank:
     it, summed weights at or below it (mc_rank_runs_build) -- which is all ``bisect_right`` ever reads; the sorted
     keys and the positions are written only when somebody looks at ``keys_sorted`` / ``positions``.  Keys that do
     not repeat do not suit that index (mc_rank_runs_check says so): the build then falls back to
-    ``index="sorted"``, the expanded arrays of mc_rank_build, which sort anything.  A caller that brings its own
+    ``index="sorted"``, the expanded arrays of mc_rank_build, which sort anything, and the process remembers the size
+    (``runs_index_wanted``): later default builds of that many keys or more go there directly.  A caller that brings its own
     buffers (``runs=`` or ``keys_sorted=`` / ``positions=``) decides the kind by that and checks the build itself
     (``check()``): nothing waits for the GPU here."""
 
@@ -263,6 +278,8 @@ class DeviceRank:
             if runs is None:                                  # the library's own buffers: settle the kind now
                 rc = self._runs_status()[0]
                 if rc == nv.ERR_UNSUITED:
+                    prev = _PREFER_SORTED_FROM[0]             # (this size and larger: the expanded arrays from now on)
+                    _PREFER_SORTED_FROM[0] = self.n if prev is None else min(prev, self.n)
                     self.runs = None                          # keys that do not repeat: the expanded arrays sort anything
                 else:
                     nv.check(rc)

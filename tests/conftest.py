@@ -15,6 +15,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _fresh_rank_choices():
+    """DeviceRank remembers, per process, from which size on the run index did not pay (engine.runs_index_wanted):
+    every test starts without that memory."""
+    try:
+        from montecarlo_amd import engine
+        engine.forget_rank_choices()
+    except Exception:                                   # (no library built: the tests that need it say so)
+        pass
+    yield
+
+
 def golden(name):
     with open(os.path.join(GOLDEN, name)) as f:
         return json.load(f)

@@ -316,3 +316,23 @@ def test_runs_index_in_two_levels_beyond_2_26_keys(model):
     nv.check(nv.lib.mc_rank_runs_query(_vp(r.vals), _vp(r.cum_count), _vp(r.cum_pos), _vp(r.info), _vp(x), 3, _vp(qp),
                                        _vp(qc), _stream(dev)))
     assert bool(torch.isnan(qp).all()) and bool((qc == 0).all())
+
+
+def test_a_refusal_is_remembered_by_size():
+    """Samples of a sub-word model (a million distinct values in 1e7 samples): the run index refuses them (here 4e6
+    samples), DeviceRank builds the expanded arrays instead and remembers the size (engine.runs_index_wanted): the
+    next default build of that many keys goes to mc_rank_build directly, smaller ones still try the index, and
+    forget_rank_choices() starts over."""
+    from montecarlo_amd import engine
+    m = BackWordsMonteCarlo(synth.as_file(synth.subword_corpus(100000)), splitter="\t", threshold=10)
+    n = 4_000_000
+    keys = m._dev.sample(n, 5, first_id=3 * n)["ml2p"]
+    rc, info, _ = build_runs(keys)
+    assert rc == nv.ERR_UNSUITED and info[1] & 1                # (a bin of more values than its tables take)
+    assert engine.runs_index_wanted(n)
+    first = DeviceRank(keys)
+    assert first.runs is None and first.check()["index"] == "sorted"
+    assert torch.equal(first.keys_sorted.view(torch.int64), torch.sort(keys)[0].view(torch.int64))
+    assert not engine.runs_index_wanted(n) and not engine.runs_index_wanted(2 * n) and engine.runs_index_wanted(n - 1)
+    engine.forget_rank_choices()
+    assert engine.runs_index_wanted(n)

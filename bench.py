@@ -40,7 +40,8 @@ os.environ.setdefault("TQDM_DISABLE", "1")
 
 from montecarlo_amd import synth  # noqa: E402
 from montecarlo_amd.backwords_simulator import BackWordsMonteCarlo  # noqa: E402
-from montecarlo_amd.engine import DeviceRank, RunsBuffers, device_guess_numbers, device_order  # noqa: E402
+from montecarlo_amd.engine import (DeviceRank, RunsBuffers, device_guess_numbers, device_order,  # noqa: E402
+                                  device_query_guess_numbers)
 from montecarlo_amd import _native as nv  # noqa: E402
 from montecarlo_amd import dist as mcd  # noqa: E402
 
@@ -183,6 +184,9 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the legs after the timed region that run BASELINE configs 3, 4, 5 and the sub-word "
                          "scorer once at their per-GPU sizes (`other_configs` in the JSON line; about a minute)")
+    ap.add_argument("--no-fused-query", action="store_true",
+                    help="one GPU, run index: answer the queries in a launch of their own (mc_rank_runs_query + "
+                         "mc_guess_numbers, three launches) instead of inside the guess numbers' first kernel")
     ap.add_argument("--time-every", type=int, default=1,
                     help="record the stage events (stage_ms, the roofline's kernel_ms) in every K-th timed step only: "
                          "each recorded event is a host call and a barrier packet on the queue")
@@ -331,9 +335,21 @@ def main():
         else:
             main_stream.wait_event(marks[6])
             marks[5].record()
-        rk.query(t_sorted[slot], out_pos=q_pos[slot], out_cnt=q_cnt)
-        marks[7].record()
-        if world == 1:
+        fused = world == 1 and rk.runs is not None and not args.no_fused_query
+        if fused:
+            # one GPU, run index: the bisection inside the guess numbers' first kernel (mc_rank_runs_guess_numbers:
+            # two launches where query + guess numbers are three); timed as one stage, under `guess_numbers`
+            marks[7] = marks[5]
+            device_query_guess_numbers(rk, t_sorted[slot], True, out_pos=q_pos[slot], out_cnt=q_cnt, out=g_rank[slot],
+                                       workspace=ws_gn, exact=g_exact[slot])
+            marks[8].record()
+            ready = marks[8]
+        else:
+            rk.query(t_sorted[slot], out_pos=q_pos[slot], out_cnt=q_cnt)
+            marks[7].record()
+        if fused:
+            pass
+        elif world == 1:
             device_guess_numbers(q_pos[slot], q_cnt, True, out=g_rank[slot], workspace=ws_gn, exact=g_exact[slot])
             marks[8].record()
             ready = marks[8]
@@ -535,6 +551,9 @@ def main():
                        "samples_per_gpu": N, "test_pwds": T, "contexts": int(flat.info[nv.INFO_NCTX]),
                        "entries": int(flat.info[nv.INFO_NENT]), "table_bytes": int(flat.info[nv.INFO_DEVICE_BYTES])},
             "stage_ms": ms, "test_set_on_second_stream": side is not None,
+            # (one GPU + run index: the queries are answered inside the guess numbers' first kernel; stage `query` is 0
+            # and `guess_numbers` holds both)
+            "query_inside_guess_numbers": world == 1 and runs_buf is not None and not args.no_fused_query,
             # one step alone and waited for: the first of the process (code objects load, allocator warms up) and one
             # after the timed region with every workspace's hint forgotten (what ONE estimate costs a caller)
             "first_step_ms": first_step_ms, "cold_step_ms": cold_step_ms,

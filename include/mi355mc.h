@@ -489,7 +489,7 @@ int mc_rank_build_noalloc(const double *keys_in, uint64_t n, uint64_t n_global, 
  * and the 1.25e9 samples of the v2 6-gram model are refused (their highest value ranges hold a million keys that
  * are all distinct): nothing takes it by default.  Keys that do not repeat
  * (more than 2048 distinct values in one of the 1024 equal parts of the value range: uniform random numbers) do
- * not suit the index: the build then marks it failed (error word set, D = 0, every query answers NaN) and
+ * not suit the index: the build then marks it failed (error word set, D = 0, every query answers NaN, count all ones) and
  * mc_rank_runs_check returns MC_ERR_UNSUITED -- the caller builds with mc_rank_build instead, which sorts anything
  * (montecarlo_amd.engine.DeviceRank does).  The workspace carries the heavy values and the value range of one
  * build to the next build of n keys (as mc_rank_build's does; results never depend on it); mc_rank_runs_forget
@@ -506,7 +506,8 @@ int mc_rank_runs_forget(void *workspace, uint64_t n, void *stream);
 int mc_rank_runs_check(const uint64_t *info, void *stream, uint64_t host_info[8]);
 /* ml2p2rank (lib4mc/MonteCarloLib.py:30-32) on the run index: out_cnt = bisect_right(sorted keys, x) =
  * cum_count of the last run at or below x (0: none), out_pos = its cum_pos (0.0: none) -- what mc_rank_query
- * returns on the arrays of mc_rank_build.  A failed index answers NaN / 0. */
+ * returns on the arrays of mc_rank_build.  A failed index answers NaN with a count of all ones (never 0: a count of 0
+ * reads "no sample at or below x", whose estimate is 1 -- a guess number). */
 int mc_rank_runs_query(const double *vals, const uint64_t *cum_count, const double *cum_pos, const uint64_t *info,
                        const double *x, uint64_t t, double *out_pos, uint64_t *out_cnt, void *stream);
 /* The arrays the reference keeps (lib4mc/MonteCarloLib.py:11, :24-27), written from the runs for callers that
@@ -572,6 +573,15 @@ int mc_order_keys(const double *x, uint64_t t, double *x_sorted, uint32_t *order
 size_t mc_guess_numbers_workspace_bytes(uint64_t t);
 int mc_guess_numbers(const double *pos, const uint64_t *cnt, uint64_t t, int add1, int64_t *out_rank,
                      uint64_t *out_exact, void *workspace, size_t workspace_bytes, void *stream);
+/* ml2p_iter2gc as the reference writes it -- the bisection inside the loop over the passwords
+ * (lib4mc/MonteCarloLib.py:47-55) -- on the run index: what mc_rank_runs_query followed by mc_guess_numbers computes
+ * (out_pos, out_cnt, out_rank, out_exact: bit for bit the same), in two launches instead of three; x in ascending
+ * order (mc_order_keys), workspace as mc_guess_numbers takes it.  For one GPU: shards sum out_pos before ranking
+ * (mc_allreduce_rank) and keep the two calls. */
+int mc_rank_runs_guess_numbers(const double *vals, const uint64_t *cum_count, const double *cum_pos, const uint64_t *info,
+                               const double *x, uint64_t t, int add1, double *out_pos, uint64_t *out_cnt,
+                               int64_t *out_rank, uint64_t *out_exact, void *workspace, size_t workspace_bytes,
+                               void *stream);
 
 /* ---- threshold enumeration ------------------------------------------------------------------*/
 /* Replaces the recursive enumerators (nwords/nwords_enumerator.py:15-42 `enumerator`/`iterate` for a

@@ -143,6 +143,7 @@ def _load() -> C.CDLL:
         "mc_rank_runs_expand": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.c_uint64, vp, vp, vp]),
         "mc_rank_runs_debug_phases": (C.c_int, [C.c_int, u64p]),
         "mc_rank_runs_debug_groups": (C.c_int, [vp, C.c_uint64, u64p, vp]),
+        "mc_rank_runs_guess_numbers": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64, C.c_int, vp, vp, vp, vp, vp, C.c_size_t, vp]),
         "mc_score_words_debug_kernel": (None, [C.c_int]),
         "mc_score_bpe_debug_kernel": (None, [C.c_int]),
     }
@@ -198,7 +199,7 @@ EXPORTS = ["mc_abi_version", "mc_last_error", "mc_table_compile", "mc_table_free
            "mc_enum_free", "mc_rank_runs_workspace_bytes", "mc_rank_runs_capacity", "mc_rank_runs_max_keys", "mc_rank_runs_build",
            "mc_rank_runs_forget", "mc_rank_runs_check", "mc_rank_runs_query", "mc_rank_runs_expand", "mc_rank_runs_debug_phases",
            "mc_score_words_debug_kernel", "mc_score_bpe_debug_kernel",
-           "mc_rank_runs_debug_groups"]
+           "mc_rank_runs_debug_groups", "mc_rank_runs_guess_numbers"]
 
 
 def check(rc: int) -> int:

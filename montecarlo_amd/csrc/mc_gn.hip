@@ -36,6 +36,7 @@ typedef long long i64;
 
 constexpr int GN_THREADS = 256, GN_ITEMS = 8, GN_TILE = GN_THREADS * GN_ITEMS, GN_MAX_BLOCKS = 1024;
 constexpr i64 GN_NEG = -(1ll << 62);
+constexpr int GN_SUB = 4;  // workgroups a chunk in k_query_chunk_max (a search wants more lanes in flight than a scan)
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -303,10 +304,98 @@ __global__ void __launch_bounds__(GN_THREADS) k_gn_chunk_max(const double *__res
     }
 }
 
+// the queries of a quarter chunk answered (k_query<RUNS> of mc_rank.hip: same search, same outputs) and folded into the
+// chunk maxima of k_gn_chunk_max; entry blockIdx.x of partials / first_bad_of
+__global__ void __launch_bounds__(GN_THREADS) k_query_chunk_max(const double *__restrict__ vals, const u64 *__restrict__ ccum,
+                                                                const double *__restrict__ wcum, const u64 *__restrict__ info,
+                                                                const double *__restrict__ x, u64 t, u64 chunk, int add1,
+                                                                double *__restrict__ out_pos, u64 *__restrict__ out_cnt,
+                                                                i64 *__restrict__ partials, u64 *__restrict__ first_bad_of) {
+    __shared__ i64 wave_tot[GN_THREADS / 64];
+    __shared__ u64 wave_bad[GN_THREADS / 64];
+    const int lane = threadIdx.x & 63;
+    const u64 c0 = (u64)(blockIdx.x / GN_SUB) * chunk, c1 = c0 + chunk < t ? c0 + chunk : t;
+    const u64 part = chunk / GN_SUB;  // (chunk is a multiple of GN_TILE: whole waves)
+    const u64 lo_q = c0 + (u64)(blockIdx.x % GN_SUB) * part, hi_q = lo_q + part < c1 ? lo_q + part : c1;
+    const u64 n = info[0];
+    const bool failed = info[1] != 0;  // a failed build must not pass for a result
+    i64 m = GN_NEG;
+    u64 bad = ~0ull;
+    for (u64 q0 = lo_q + (threadIdx.x - lane); q0 < hi_q; q0 += GN_THREADS) {
+        const u64 q = q0 + lane;
+        const bool act = q < hi_q;
+        const double v = act ? x[q] : 0.0;
+        double vmin = act ? v : __longlong_as_double(0x7FF0000000000000ll);
+        double vmax = act ? v : __longlong_as_double(0xFFF0000000000000ull);
+        const bool odd = act && !(v == v);
+#pragma unroll
+        for (int o = 32; o; o >>= 1) {
+            const double a2 = __shfl_xor(vmin, o), b2 = __shfl_xor(vmax, o);
+            vmin = a2 < vmin ? a2 : vmin;
+            vmax = b2 > vmax ? b2 : vmax;
+        }
+        u64 lo = 0, hi = failed ? 0 : n;
+        if (!failed && __ballot(odd) == 0 && n > 4096) {
+            const double w = lane < 32 ? vmin : vmax;
+            const int sub = lane & 31;
+            u64 a = 0, b = n;
+            while (b - a > 64) {
+                const u64 step = (b - a) / 33 + 1;
+                const u64 p = a + step * (u64)(sub + 1) - 1;
+                const bool gt = p < b ? vals[p] > w : true;
+                const u64 bal = __ballot(gt);
+                const u32 half = lane < 32 ? (u32)bal : (u32)(bal >> 32);
+                const int first = half ? __ffs((int)half) - 1 : 32;
+                const u64 nb2 = first < 32 ? a + step * (u64)(first + 1) - 1 : b;
+                const u64 na = first > 0 ? a + step * (u64)first : a;
+                a = na;
+                b = nb2 < b ? nb2 : b;
+            }
+            lo = __shfl(a, 0);
+            hi = __shfl(b, 32);
+        }
+        if (act) {
+            while (lo < hi) {  // first index with vals[i] > v  (bisect_right)
+                const u64 mid = (lo + hi) >> 1;
+                if (vals[mid] > v) hi = mid; else lo = mid + 1;
+            }
+            const u64 c = failed ? ~0ull : (lo ? ccum[lo - 1] : 0ull);  // (as k_query<RUNS>: never an estimate of 1)
+            const double p = failed ? __longlong_as_double(0x7FF8000000000000ll) : (lo ? wcum[lo - 1] : 0.0);
+            out_cnt[q] = c;
+            out_pos[q] = p;
+            // (gn_term on the values just written)
+            const double ce = ceil(c > 0 ? p : 1.0);
+            i64 term;
+            if (!(ce < 4611686018427387904.0)) {
+                bad = q < bad ? q : bad;
+                term = GN_NEG;
+            } else {
+                term = (i64)ce - (add1 ? (i64)(q + 1) : 0);
+                term = term > 0 ? term : 0;
+            }
+            m = term > m ? term : m;
+        }
+    }
+    i64 tot;
+    (void)block_max_scan_excl(m, wave_tot, tot);
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        const u64 u = __shfl_xor(bad, o);
+        bad = u < bad ? u : bad;
+    }
+    if (lane == 0) wave_bad[threadIdx.x >> 6] = bad;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < GN_THREADS / 64; ++w) bad = wave_bad[w] < bad ? wave_bad[w] : bad;
+        partials[blockIdx.x] = tot;
+        first_bad_of[blockIdx.x] = bad;
+    }
+}
+
 __global__ void __launch_bounds__(GN_THREADS) k_gn_ranks(const double *__restrict__ pos, const u64 *__restrict__ cnt,
                                                          u64 t, u64 chunk, int add1, const i64 *__restrict__ partials,
                                                          const u64 *__restrict__ first_bad_of, u32 nb, u64 *out_exact,
-                                                         i64 *__restrict__ rank) {
+                                                         i64 *__restrict__ rank, u32 sub) {
     __shared__ i64 wave_tot[GN_THREADS / 64];
     __shared__ u64 wave_bad[GN_THREADS / 64];
     __shared__ i64 s_carry;
@@ -315,8 +404,8 @@ __global__ void __launch_bounds__(GN_THREADS) k_gn_ranks(const double *__restric
     {
         i64 m = GN_NEG;
         u64 bad = t;  // (no estimate out of range: all t ranks are exact)
-        for (u32 i = threadIdx.x; i < nb; i += GN_THREADS) {
-            if (i < blockIdx.x) m = partials[i] > m ? partials[i] : m;
+        for (u32 i = threadIdx.x; i < nb * sub; i += GN_THREADS) {  // (`sub` entries a chunk: k_query_chunk_max's workgroups)
+            if (i < blockIdx.x * sub) m = partials[i] > m ? partials[i] : m;
             bad = first_bad_of[i] < bad ? first_bad_of[i] : bad;
         }
 #pragma unroll
@@ -454,7 +543,7 @@ extern "C" int mc_order_keys(const double *x, uint64_t t, double *x_sorted, uint
 
 extern "C" size_t mc_guess_numbers_workspace_bytes(uint64_t t) {
     (void)t;
-    return 2 * align256(GN_MAX_BLOCKS * sizeof(i64)) + 256;  // per chunk: largest term, lowest index out of range
+    return 2 * align256(GN_MAX_BLOCKS * GN_SUB * sizeof(i64)) + 256;  // per chunk (and workgroup of a chunk): largest term, lowest index out of range
 }
 
 extern "C" int mc_guess_numbers(const double *pos, const uint64_t *cnt, uint64_t t, int add1, int64_t *out_rank,
@@ -481,11 +570,52 @@ extern "C" int mc_guess_numbers(const double *pos, const uint64_t *cnt, uint64_t
     const u64 tiles = (t + GN_TILE - 1) / GN_TILE;
     const u32 nb = (u32)(tiles < (u64)GN_MAX_BLOCKS ? tiles : (u64)GN_MAX_BLOCKS);
     const u64 chunk = ((tiles + nb - 1) / nb) * GN_TILE;
-    u64 *first_bad_of = (u64 *)((char *)workspace + align256(GN_MAX_BLOCKS * sizeof(i64)));
+    u64 *first_bad_of = (u64 *)((char *)workspace + align256(GN_MAX_BLOCKS * GN_SUB * sizeof(i64)));
     hipLaunchKernelGGL(k_gn_chunk_max, dim3(nb), dim3(GN_THREADS), 0, s, pos, (const u64 *)cnt, (u64)t, chunk, add1,
                        partials, first_bad_of);
     hipLaunchKernelGGL(k_gn_ranks, dim3(nb), dim3(GN_THREADS), 0, s, pos, (const u64 *)cnt, (u64)t, chunk, add1,
-                       (const i64 *)partials, (const u64 *)first_bad_of, nb, (u64 *)out_exact, (i64 *)out_rank);
+                       (const i64 *)partials, (const u64 *)first_bad_of, nb, (u64 *)out_exact, (i64 *)out_rank, 1u);
+    HIP_TRY(hipGetLastError());
+    return MC_OK;
+}
+
+// ml2p_iter2gc as it stands in the reference -- the bisection INSIDE the loop over the passwords
+// (lib4mc/MonteCarloLib.py:47-55) -- on the run index: mc_rank_runs_query and mc_guess_numbers in two launches instead
+// of three.  The first kernel answers the queries (k_query's search: a wave brackets its 64 ascending queries in rounds
+// of 32 probes, then every lane bisects), writes pos / cnt as mc_rank_runs_query does and folds the chunk maxima of
+// mc_guess_numbers' first kernel on the way; the second is k_gn_ranks as it is.  Same outputs bit for bit.
+extern "C" int mc_rank_runs_guess_numbers(const double *vals, const uint64_t *cum_count, const double *cum_pos,
+                                          const uint64_t *info, const double *x, uint64_t t, int add1, double *out_pos,
+                                          uint64_t *out_cnt, int64_t *out_rank, uint64_t *out_exact, void *workspace,
+                                          size_t workspace_bytes, void *stream) {
+    if (!out_exact) {
+        mc_set_error("mc_rank_runs_guess_numbers: bad argument");
+        return MC_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (t == 0) {
+        HIP_TRY(hipMemsetAsync(out_exact, 0, sizeof(uint64_t), s));
+        return MC_OK;
+    }
+    if (!vals || !cum_count || !cum_pos || !info || !x || !out_pos || !out_cnt || !out_rank || !workspace) {
+        mc_set_error("mc_rank_runs_guess_numbers: bad argument");
+        return MC_ERR_ARG;
+    }
+    if (workspace_bytes < mc_guess_numbers_workspace_bytes(t)) {
+        mc_set_error("mc_rank_runs_guess_numbers: workspace of %zu bytes, need %zu", workspace_bytes,
+                     mc_guess_numbers_workspace_bytes(t));
+        return MC_ERR_WORKSPACE;
+    }
+    i64 *partials = (i64 *)workspace;
+    const u64 tiles = (t + GN_TILE - 1) / GN_TILE;
+    const u32 nb = (u32)(tiles < (u64)GN_MAX_BLOCKS ? tiles : (u64)GN_MAX_BLOCKS);
+    const u64 chunk = ((tiles + nb - 1) / nb) * GN_TILE;
+    u64 *first_bad_of = (u64 *)((char *)workspace + align256(GN_MAX_BLOCKS * GN_SUB * sizeof(i64)));
+    hipLaunchKernelGGL(k_query_chunk_max, dim3(nb * GN_SUB), dim3(GN_THREADS), 0, s, vals, (const u64 *)cum_count, cum_pos,
+                       (const u64 *)info, x, (u64)t, chunk, add1, out_pos, (u64 *)out_cnt, partials, first_bad_of);
+    hipLaunchKernelGGL(k_gn_ranks, dim3(nb), dim3(GN_THREADS), 0, s, (const double *)out_pos, (const u64 *)out_cnt, (u64)t,
+                       chunk, add1, (const i64 *)partials, (const u64 *)first_bad_of, nb, (u64 *)out_exact,
+                       (i64 *)out_rank, (u32)GN_SUB);
     HIP_TRY(hipGetLastError());
     return MC_OK;
 }

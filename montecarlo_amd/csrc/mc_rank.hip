@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(256) k_query(const double *__restrict__ keys, 
     if (RUNS && info[1]) {  // a failed build must not pass for a result
         for (u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x; q < t; q += (u64)gridDim.x * blockDim.x) {
             out_pos[q] = __longlong_as_double(0x7FF8000000000000ll);
-            if (out_cnt) out_cnt[q] = 0;
+            if (out_cnt) out_cnt[q] = ~0ull;  // (not 0: "no sample at or below x" makes the estimate 1, a guess number)
         }
         return;
     }

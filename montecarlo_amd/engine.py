@@ -407,6 +407,31 @@ def device_order(x: torch.Tensor, out_sorted: torch.Tensor = None, out_order: to
     return srt, order
 
 
+def device_query_guess_numbers(rk: "DeviceRank", x: torch.Tensor, add1: bool = True, out_pos: torch.Tensor = None,
+                               out_cnt: torch.Tensor = None, out: torch.Tensor = None, workspace: torch.Tensor = None,
+                               exact: torch.Tensor = None):
+    """rk.query(x) and device_guess_numbers in one call (mc_rank_runs_guess_numbers: two launches, not three) when
+    ``rk`` holds a run index; otherwise the two calls.  -> (pos, cnt, ranks, exact)."""
+    t = x.numel()
+    dev = x.device
+    with torch.cuda.device(dev):
+        pos = out_pos if out_pos is not None else torch.empty(t, dtype=torch.float64, device=dev)
+        cnt = out_cnt if out_cnt is not None else torch.empty(t, dtype=torch.int64, device=dev)
+        if rk.runs is None:
+            rk.query(x, out_pos=pos, out_cnt=cnt)
+            ranks, ex, _ = device_guess_numbers(pos, cnt, add1, out=out, workspace=workspace, exact=exact)
+            return pos, cnt, ranks, ex
+        ranks = out if out is not None else torch.empty(t, dtype=torch.int64, device=dev)
+        ex = exact if exact is not None else torch.empty(1, dtype=torch.int64, device=dev)
+        ws = workspace if workspace is not None else torch.empty(nv.lib.mc_guess_numbers_workspace_bytes(t),
+                                                                 dtype=torch.uint8, device=dev)
+        r = rk.runs
+        nv.check(nv.lib.mc_rank_runs_guess_numbers(_vp(r.vals), _vp(r.cum_count), _vp(r.cum_pos), _vp(r.info), _vp(x), t,
+                                                   1 if add1 else 0, _vp(pos), _vp(cnt), _vp(ranks), _vp(ex), _vp(ws),
+                                                   ws.numel(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return pos, cnt, ranks, ex
+
+
 def device_guess_numbers(pos: torch.Tensor, cnt: Optional[torch.Tensor], add1: bool = True,
                          out: torch.Tensor = None, workspace: torch.Tensor = None, exact: torch.Tensor = None):
     """mc_guess_numbers on device vectors in ascending order of -log2 p: (ranks int64, exact) where ``exact`` is a

@@ -116,15 +116,17 @@ class MonteCarloLib:
         """rank_i = ceil(max(estimate_i, rank_{i-1} + add)), rank_0 = 0 (reference :47-55), in the order given:
         int64 array from the device (mc_guess_numbers), or a list of Python ints when some guess number
         exceeds int64 -- those, a suffix in ascending order, are finished with the reference's own expression."""
-        from ..engine import device_guess_numbers
+        from ..engine import device_guess_numbers, device_query_guess_numbers
         rk = self.__rank
         x = torch.from_numpy(numpy.ascontiguousarray(mlps, dtype=numpy.float64)).to(rk.tdev)
-        pos, cnt = rk.query(x)
-        if self.__group is not None:
+        if self.__group is None:
+            # (one GPU: the bisection inside the loop, as the reference writes it -- mc_rank_runs_guess_numbers)
+            _pos, _cnt, ranks_d, exact_d = device_query_guess_numbers(rk, x, add1)
+        else:
+            pos, _cnt = rk.query(x)
             # every weight is positive: the summed position is > 0 exactly when some shard counted a sample
             torch.distributed.all_reduce(pos, group=self.__group)
-            cnt = None
-        ranks_d, exact_d, _ws = device_guess_numbers(pos, cnt, add1)
+            ranks_d, exact_d, _ws = device_guess_numbers(pos, None, add1)
         ranks = ranks_d.cpu().numpy()
         exact = int(exact_d.item())
         if exact >= len(mlps):

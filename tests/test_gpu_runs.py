@@ -211,7 +211,7 @@ def test_runs_index_refuses_keys_that_do_not_repeat(model):
     qp, qc = torch.zeros_like(x), torch.ones(3, dtype=torch.int64, device=dev)
     nv.check(nv.lib.mc_rank_runs_query(_vp(r.vals), _vp(r.cum_count), _vp(r.cum_pos), _vp(r.info), _vp(x), 3, _vp(qp),
                                        _vp(qc), _stream(dev)))
-    assert bool(torch.isnan(qp).all()) and bool((qc == 0).all())
+    assert bool(torch.isnan(qp).all()) and bool((qc == -1).all())
     rk = DeviceRank(keys)
     assert rk.runs is None and rk.check()["index"] == "sorted"
     assert torch.equal(rk.keys_sorted.view(torch.int64), torch.sort(keys)[0].view(torch.int64))
@@ -315,7 +315,7 @@ def test_runs_index_in_two_levels_beyond_2_26_keys(model):
     qp, qc = torch.zeros_like(x), torch.ones(3, dtype=torch.int64, device=dev)
     nv.check(nv.lib.mc_rank_runs_query(_vp(r.vals), _vp(r.cum_count), _vp(r.cum_pos), _vp(r.info), _vp(x), 3, _vp(qp),
                                        _vp(qc), _stream(dev)))
-    assert bool(torch.isnan(qp).all()) and bool((qc == 0).all())
+    assert bool(torch.isnan(qp).all()) and bool((qc == -1).all())
 
 
 def test_a_refusal_is_remembered_by_size():
@@ -336,3 +336,36 @@ def test_a_refusal_is_remembered_by_size():
     assert not engine.runs_index_wanted(n) and not engine.runs_index_wanted(2 * n) and engine.runs_index_wanted(n - 1)
     engine.forget_rank_choices()
     assert engine.runs_index_wanted(n)
+
+
+def test_query_inside_the_guess_numbers_equals_the_two_calls(model):
+    """mc_rank_runs_guess_numbers (ml2p_iter2gc as the reference writes it: the bisection inside the loop) against
+    mc_rank_runs_query followed by mc_guess_numbers: positions, counts, guess numbers and the count of exact ones bit
+    for bit -- ascending queries of several sizes (chunk borders, a last partial wave), queries below every key and
+    above every key, add1 on and off, a NaN query, and a failed index (NaN positions, no exact guess number)."""
+    from montecarlo_amd.engine import device_guess_numbers, device_query_guess_numbers
+    dev = torch.device("cuda")
+    keys = model._dev.sample(3_000_000, 31)["ml2p"]
+    rk = DeviceRank(keys, n_global=3 * keys.numel(), index="runs")
+    assert rk.check()["error"] == 0
+    g = torch.Generator(device="cpu").manual_seed(4)
+    for t in (1, 63, 64, 65, 2047, 2048, 2049, 100_003, 1_000_000):
+        x = torch.sort(torch.cat([keys[torch.randint(0, keys.numel(), (t,), generator=g).to(dev)][: max(1, t - 3)],
+                                  torch.tensor([0.5, 200.0, 1022.0], dtype=torch.float64, device=dev)])[:t]).values.contiguous()
+        for add1 in (True, False):
+            p0, c0 = rk.query(x)
+            r0, e0, _ = device_guess_numbers(p0, c0, add1)
+            p1, c1, r1, e1 = device_query_guess_numbers(rk, x, add1)
+            torch.cuda.synchronize()
+            assert torch.equal(p0.view(torch.int64), p1.view(torch.int64)) and torch.equal(c0, c1), (t, add1)
+            assert torch.equal(r0, r1) and int(e0.item()) == int(e1.item()), (t, add1)
+    x = torch.tensor([5.0, float("nan"), 30.0], dtype=torch.float64, device=dev)       # (no order: any x is answered)
+    p0, c0 = rk.query(x)
+    r0, e0, _ = device_guess_numbers(p0, c0, True)
+    p1, c1, r1, e1 = device_query_guess_numbers(rk, x, True)
+    assert torch.equal(p0.view(torch.int64), p1.view(torch.int64)) and torch.equal(c0, c1) and torch.equal(r0, r1)
+    noise = (torch.rand(3_000_000, dtype=torch.float64) * 60 + 5).to(dev)
+    bad = DeviceRank(noise, runs=RunsBuffers(3_000_000, noise.device))
+    x = torch.tensor([10.0, 20.0, 30.0], dtype=torch.float64, device=dev)
+    p1, c1, r1, e1 = device_query_guess_numbers(bad, x, True)
+    assert bool(torch.isnan(p1).all()) and bool((c1 == -1).all()) and int(e1.item()) == 0       # (never the estimate 1)

@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(256) k_order_out(const u64 *__restrict__ words
 // estimate_i = pos[i] if the bisection counted a sample, else 1 (lib4mc/MonteCarloLib.py:53)
 __device__ __forceinline__ double gn_estimate(const double *pos, const u64 *cnt, u64 i) {
     const double p = pos[i];
-    return (cnt ? cnt[i] > 0 : p > 0.0) ? p : 1.0;
+    return (cnt ? cnt[i] > 0 : !(p <= 0.0)) ? p : 1.0;  // (a NaN position stays NaN: never the estimate 1)
 }
 
 // ceil(est) - i * add as int64, or GN_NEG for an estimate that does not fit (first_bad keeps the lowest such index)

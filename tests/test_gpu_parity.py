@@ -515,6 +515,12 @@ def test_guess_numbers_equal_reference_loop():
                 assert np.array_equal(got[exact:].view(np.float64), np.where(cnt > 0, pos, 1.0)[exact:])
     ranks, exact, _ = device_guess_numbers(torch.empty(0, dtype=torch.float64, device="cuda"), None, True)
     assert int(exact.item()) == 0
+    # a NaN position (a failed index, or one shard's in the sum of all shards) is never read as "no sample at or
+    # below": the exact prefix ends there, with and without counts
+    pos = torch.tensor([3.0, 5.0, float("nan"), 9.0], dtype=torch.float64, device="cuda")
+    for cnt in (None, torch.ones(4, dtype=torch.int64, device="cuda")):
+        ranks, exact, _ = device_guess_numbers(pos, cnt, True)
+        assert int(exact.item()) == 2 and ranks[:2].tolist() == [3, 5]
 
 
 def test_driver_flow_on_columns_equals_tuple_flow(big_model):

@@ -486,6 +486,55 @@ def test_order_keys_is_pythons_stable_sort():
     assert torch.equal(order.long() & 0xFFFFFFFF, want[1]) and torch.equal(srt, want[0])
 
 
+def test_order_keys_places_groups_of_every_size():
+    """Passwords that share a score keep their input order whatever the size of the group: test sets made of groups
+    of 2, up to 8, up to 64, up to 512 and thousands of equal scores, Zipf-sized groups like the bench's test set
+    (of its 1e6 passwords 145,000 are one password), groups larger than 2^18, tiny inputs that are one group, and one
+    workspace serving several calls.  (Written for a second half of mc_order_keys that placed the groups by counting
+    and then put each in order by one of four routes; it was correct and slower than the stable LSD passes on both
+    unique and heavily repeated test sets -- DESIGN.md 3.6 -- so the passes stay, with these cases.)"""
+    from montecarlo_amd.engine import device_order
+    rng = np.random.default_rng(77)
+
+    def groups(sizes):
+        vals = rng.permutation(len(sizes)).astype(np.float64) * 0.37 + 1.0
+        x = np.repeat(vals, sizes)
+        return x[rng.permutation(x.size)]
+
+    zipf = np.minimum(rng.zipf(1.3, 20000), 150000)
+    cases = {
+        "pairs": groups(np.full(40000, 2)),
+        "up to 8": groups(rng.integers(1, 9, 30000)),
+        "9 to 64": groups(rng.integers(9, 65, 4000)),
+        "65 to 512": groups(rng.integers(65, 513, 600)),
+        "513 and more": groups(rng.integers(513, 5000, 90)),
+        "mixed": groups(np.concatenate([np.full(50000, 1), rng.integers(2, 9, 5000), rng.integers(9, 65, 800),
+                                        rng.integers(65, 513, 100), [513, 30000, 144633]])),
+        "zipf": groups(zipf[: np.searchsorted(np.cumsum(zipf), 900000)]),
+        "three windows": groups(np.array([300000, 280000, 1, 2, 9, 70, 600, 250000])),
+        "nine": np.full(9, 2.5),
+        "600": np.full(600, 2.5),
+        "513 then one": np.concatenate([np.full(513, 7.0), [3.0]]),
+        "2^18 + 7 equal": np.full((1 << 18) + 7, 1.5),
+    }
+    for name, x in cases.items():
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        srt, order = device_order(torch.from_numpy(x).cuda())
+        want = np.argsort(x, kind="stable")
+        assert np.array_equal(order.cpu().numpy().view(np.uint32), want.astype(np.uint32)), name
+        assert np.array_equal(srt.cpu().numpy().view(np.uint64), x[want].view(np.uint64)), name
+    # the same workspace again with other keys
+    ws = None
+    for seed in (1, 2, 3):
+        x = torch.from_numpy(np.round(np.random.default_rng(seed).random(250000) * 300, 0)).cuda()
+        if ws is None:
+            from montecarlo_amd import _native as nv
+            ws = torch.empty(nv.lib.mc_order_workspace_bytes(x.numel()), dtype=torch.uint8, device="cuda")
+        srt, order = device_order(x, workspace=ws)
+        want = torch.sort(x, stable=True)
+        assert torch.equal(order.long() & 0xFFFFFFFF, want[1]) and torch.equal(srt, want[0])
+
+
 def test_guess_numbers_equal_reference_loop():
     """mc_guess_numbers == the reference's running expression rank = ceil(max(estimate, prev + add))
     (lib4mc/MonteCarloLib.py:47-55) on ascending estimates, across chunk borders, with estimates that do not

@@ -64,7 +64,7 @@ def per_stage(rs):
             stage = "mc_order_keys"          # (the first kernel after the scoring: the order's key sort)
         elif base == "k_query":
             stage = "k_query"
-        elif base.startswith("k_gn_"):
+        elif base.startswith("k_gn_") or base == "k_query_chunk_max":   # (mc_rank_runs_guess_numbers: the bisection inside)
             stage = "mc_guess_numbers"
         elif stage == "k_sample":
             stage = "mc_rank_build"          # (the first kernel after the sampler: the sort's memset or k_sniff)

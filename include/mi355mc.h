@@ -153,7 +153,8 @@ enum {
     MC_INFO_TRANS_CAP = 5, MC_INFO_CTX_CAP = 6, MC_INFO_GUIDE_LEN = 7, MC_INFO_DEVICE_BYTES = 8,
     MC_INFO_MAX_ROW = 9, MC_INFO_KIND = 10, MC_INFO_MULTICHAR = 11, MC_INFO_START_DRAW = 12,
     MC_INFO_DIRECT_BUCKETS = 13, MC_INFO_ONE_BUCKETS = 14, MC_INFO_MULTI_BUCKETS = 15
-};  /* info[11] (MC_INFO_MULTICHAR) bit 0: some symbol is not one character; bits 8..: longest symbol text */
+};  /* info[11] (MC_INFO_MULTICHAR) bit 0: some symbol is not one character; bit 1: the draw records carry the
+     symbols' lengths (MC_DRAW_LEN_SHIFT); bits 8..: longest symbol text */
 /* 64-bit hash of a context (sequence of unit ids) as stored in the context index. */
 uint64_t mc_ctx_hash(const uint32_t *units, uint32_t n);
 /* 64-bit hash of a symbol's text (code points) as stored in the word index. */
@@ -198,6 +199,13 @@ enum { MC_DRAW_DIRECT = 0, MC_DRAW_ONE = 1, MC_DRAW_MULTI = 2 };
 #define MC_DRAW_TYPE(meta) (((meta) >> 29) & 3u)
 #define MC_DRAW_GBITS(meta) (((meta) >> 24) & 31u)
 #define MC_DRAW_SYM(meta) ((meta) & 0x00FFFFFFu)
+/* Models whose symbols are not all one character (info[MC_INFO_MULTICHAR] bit 0) and whose draw table has fewer
+ * than 2^26 - 1 buckets keep the symbol's length beside the next row (info[MC_INFO_MULTICHAR] bit 1): word 2 of a
+ * DIRECT record that is not the end symbol's = characters of the symbol << 26 | the next row's first bucket
+ * (MC_DRAW_OFF_MASK: no next row), so the sampler's length count needs no read of its own. */
+#define MC_DRAW_LEN_SHIFT 26
+#define MC_DRAW_OFF_MASK 0x03FFFFFFu
+#define MC_DRAW_LEN_MAX 63u
 #define MC_MAX_SYMBOLS 0x01000000u /* symbol ids must fit the 24-bit field */
 
 typedef struct mc_draw_rec {

@@ -163,7 +163,9 @@ constexpr unsigned int RING_LINES = 8;    // lines a wave keeps open
 constexpr unsigned int CHUNK_LINES = 4;   // lines (64 ids) a wave takes from its workgroup's cursor at a time
 constexpr unsigned int RING_CHUNKS = 4;   // chunk starts a wave remembers (> RING_LINES / CHUNK_LINES + 1)
 
-template <bool INJECT, bool MULTICHAR, int NC>
+// CHARS: how a symbol's length is known -- 0 every symbol is one character, 1 read from sym_chars, 2 carried by the
+// draw record (MC_DRAW_LEN_SHIFT)
+template <bool INJECT, int CHARS, int NC>
 __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
     // the head of the draw table (the rows with the most visits per bucket: mc_table.cpp places them
     // first) lives in LDS: a.hot_recs records, loaded once per workgroup
@@ -393,8 +395,14 @@ __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
                     const uint32_t s = MC_DRAW_SYM(q[c].w3);
                     if (sym_row[c] && nsym[c] < a.sym_stride) sym_row[c][nsym[c]] = s;
                     ++nsym[c];
-                    plen[c] += MULTICHAR ? m.sym_chars[s] : 1u;
-                    goff[c] = q[c].w2;
+                    if (CHARS == 2) {
+                        const uint32_t off = q[c].w2 & MC_DRAW_OFF_MASK;
+                        plen[c] += q[c].w2 >> MC_DRAW_LEN_SHIFT;
+                        goff[c] = off == MC_DRAW_OFF_MASK ? MC_NONE : off;
+                    } else {
+                        plen[c] += CHARS ? m.sym_chars[s] : 1u;
+                        goff[c] = q[c].w2;
+                    }
                     gbits[c] = MC_DRAW_GBITS(q[c].w3);
                     if (plen[c] >= m.max_len) restart = true;
                 }
@@ -1493,7 +1501,7 @@ struct mc_model {
     void *arena;
     size_t arena_bytes;
     DevModel dev;
-    bool multichar;
+    bool multichar, len_in_rec;
     // mc_sample_tune: launch geometry of k_sample (0 / negative: the library's defaults)
     int tune_wg_per_cu = 0, tune_hot_kb = -1;
     float tune_skew = -1.0f;
@@ -1512,6 +1520,7 @@ extern "C" int mc_model_upload(const mc_table *t, int device, mc_model **out) {
     if (!m) return MC_ERR_NOMEM;
     m->device = device;
     m->multichar = t->multichar;
+    m->len_in_rec = t->len_in_rec;
     m->has_text = !t->wordhash.empty();
     m->n_draw = t->draw.size();
     m->arena_bytes = mc_table_device_bytes(t);
@@ -1697,15 +1706,19 @@ static int launch_sample(mc_model *m, bool inject, const SampleArgs &a_in, hipSt
     }
     dim3 g((unsigned)grid), b(256);
     if (inject) {
-        if (m->multichar) hipLaunchKernelGGL((k_sample<true, true, 1>), g, b, lds, s, m->dev, a);
-        else hipLaunchKernelGGL((k_sample<true, false, 1>), g, b, lds, s, m->dev, a);
+        if (m->len_in_rec) hipLaunchKernelGGL((k_sample<true, 2, 1>), g, b, lds, s, m->dev, a);
+        else if (m->multichar) hipLaunchKernelGGL((k_sample<true, 1, 1>), g, b, lds, s, m->dev, a);
+        else hipLaunchKernelGGL((k_sample<true, 0, 1>), g, b, lds, s, m->dev, a);
+    } else if (m->len_in_rec) {
+        if (nc == 2) hipLaunchKernelGGL((k_sample<false, 2, 2>), g, b, lds, s, m->dev, a);
+        else hipLaunchKernelGGL((k_sample<false, 2, 1>), g, b, lds, s, m->dev, a);
     } else if (m->multichar) {
-        if (nc == 2) hipLaunchKernelGGL((k_sample<false, true, 2>), g, b, lds, s, m->dev, a);
-        else hipLaunchKernelGGL((k_sample<false, true, 1>), g, b, lds, s, m->dev, a);
+        if (nc == 2) hipLaunchKernelGGL((k_sample<false, 1, 2>), g, b, lds, s, m->dev, a);
+        else hipLaunchKernelGGL((k_sample<false, 1, 1>), g, b, lds, s, m->dev, a);
     } else {
-        if (nc == 2) hipLaunchKernelGGL((k_sample<false, false, 2>), g, b, lds, s, m->dev, a);
-        else if (nc == 4) hipLaunchKernelGGL((k_sample<false, false, 4>), g, b, lds, s, m->dev, a);
-        else hipLaunchKernelGGL((k_sample<false, false, 1>), g, b, lds, s, m->dev, a);
+        if (nc == 2) hipLaunchKernelGGL((k_sample<false, 0, 2>), g, b, lds, s, m->dev, a);
+        else if (nc == 4) hipLaunchKernelGGL((k_sample<false, 0, 4>), g, b, lds, s, m->dev, a);
+        else hipLaunchKernelGGL((k_sample<false, 0, 1>), g, b, lds, s, m->dev, a);
     }
     HIP_TRY(hipGetLastError());
     return MC_OK;

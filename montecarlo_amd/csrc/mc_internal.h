@@ -33,6 +33,7 @@ struct mc_table {
     uint32_t end_sym, min_len, max_len, flags;
     uint32_t start_state, root, max_row;
     bool multichar;
+    bool len_in_rec;  // the draw records carry the symbols' lengths (MC_DRAW_LEN_SHIFT)
     std::vector<mc_state_rec> state;
     std::vector<mc_draw_rec> draw;   // bucketed draw table (all rows)
     std::vector<mc_draw_rec> spay;   // per-entry DIRECT records

@@ -223,10 +223,13 @@ extern "C" int mc_table_compile(const mc_model_desc *d, mc_table **out) {
     t->ctxhash = idx.slots;
     t->sym_chars.assign(d->n_sym, 1);
     t->multichar = false;
+    t->len_in_rec = false;
+    uint32_t longest_sym = 1;
     if (d->sym_chars)
         for (uint32_t s = 0; s < d->n_sym; ++s) {
             t->sym_chars[s] = d->sym_chars[s];
             if (d->sym_chars[s] != 1 && s != d->end_sym) t->multichar = true;
+            if (s != d->end_sym) longest_sym = std::max(longest_sym, d->sym_chars[s]);
         }
 
     const bool backoff = d->kind == MC_KIND_BACKOFF;
@@ -433,6 +436,9 @@ extern "C" int mc_table_compile(const mc_model_desc *d, mc_table **out) {
         t->start_gbits = 0;
     }
 
+    // a symbol's length beside the next row (MC_DRAW_LEN_SHIFT): the sampler's length count then costs no read
+    t->len_in_rec = t->multichar && !bpe && n_buckets < MC_DRAW_OFF_MASK && longest_sym <= MC_DRAW_LEN_MAX &&
+                    !getenv("MC_NO_LEN_IN_REC");
     // ---- draw table: thresholds in the uniform's domain, per-entry records, buckets ----------
     t->rcum.resize(d->n_ent);
     t->spay.resize(d->n_ent);
@@ -456,6 +462,10 @@ extern "C" int mc_table_compile(const mc_model_desc *d, mc_table **out) {
             } else if (p.next != MC_NONE) {
                 q.w[2] = t->state[p.next].guide_off;
                 nb = t->state[p.next].gbits;
+            }
+            if (t->len_in_rec && !(p.sym & MC_DRAW_END)) {
+                const uint32_t off = q.w[2] == MC_NONE ? MC_DRAW_OFF_MASK : q.w[2];
+                q.w[2] = (t->sym_chars[p.sym & 0x00FFFFFFu] << MC_DRAW_LEN_SHIFT) | off;
             }
             q.w[3] = (p.sym & MC_DRAW_END) | ((uint32_t)MC_DRAW_DIRECT << 29) | (nb << 24) | (p.sym & 0x00FFFFFFu);
         }
@@ -683,7 +693,7 @@ extern "C" int mc_table_info(const mc_table *t, uint64_t info[16]) {
     info[MC_INFO_DEVICE_BYTES] = mc_table_device_bytes(t);
     info[MC_INFO_MAX_ROW] = t->max_row;
     info[MC_INFO_KIND] = t->kind;
-    info[MC_INFO_MULTICHAR] = (t->multichar ? 1 : 0) | ((uint64_t)t->max_word_len << 8);
+    info[MC_INFO_MULTICHAR] = (t->multichar ? 1 : 0) | (t->len_in_rec ? 2 : 0) | ((uint64_t)t->max_word_len << 8);
     info[MC_INFO_START_DRAW] = t->start_draw | ((uint64_t)t->start_gbits << 32);
     info[MC_INFO_DIRECT_BUCKETS] = t->n_direct;
     info[MC_INFO_ONE_BUCKETS] = t->n_one;

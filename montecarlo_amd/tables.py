@@ -127,6 +127,7 @@ class FlatTable:
         nv.check(nv.lib.mc_table_info(self._h, info))
         self.info = list(info)
         self.multichar = bool(self.info[nv.INFO_MULTICHAR] & 1)
+        self.len_in_rec = bool(self.info[nv.INFO_MULTICHAR] & 2)   # (the draw records carry the symbols' lengths)
         self.max_word_len = int(self.info[nv.INFO_MULTICHAR] >> 8)
         self._lut: Optional[np.ndarray] = None
 
@@ -145,6 +146,7 @@ class FlatTable:
         nv.check(nv.lib.mc_table_info(self._h, info))
         self.info = list(info)
         self.multichar = bool(self.info[nv.INFO_MULTICHAR] & 1)
+        self.len_in_rec = bool(self.info[nv.INFO_MULTICHAR] & 2)   # (the draw records carry the symbols' lengths)
         self.max_word_len = int(self.info[nv.INFO_MULTICHAR] >> 8)
         self._lut = None
         return self

@@ -99,7 +99,7 @@ def test_nwords_tab(train_tab):
     fx = golden("nwords_n3_tab.json")
     m = NWordsMonteCarlo(synth.as_file(train_tab), n=3, splitter="\t")
     check_table(fx, m)
-    assert m._flat.multichar
+    assert m._flat.multichar and m._flat.len_in_rec       # (the draw records carry the symbols' lengths: walker.sample reads them)
     check_walk(fx, m)
 
 

@@ -37,6 +37,7 @@ class CompiledWalker:
         self.max_word_len = flat.max_word_len
         self.start_draw = flat.info[nv.INFO_START_DRAW] & 0xFFFFFFFF
         self.start_gbits = flat.info[nv.INFO_START_DRAW] >> 32
+        self.len_in_rec = bool(flat.info[nv.INFO_MULTICHAR] & 2)    # (MC_DRAW_LEN_SHIFT: lengths in the draw records)
 
     @staticmethod
     def f64(q):
@@ -81,8 +82,15 @@ class CompiledWalker:
             else:
                 s = meta & 0xFFFFFF
                 syms.append(s)
-                plen += int(self.sym_chars[s])
-                goff, gbits = int(q[2]), (meta >> 24) & 31
+                if self.len_in_rec:
+                    assert int(q[2]) >> 26 == int(self.sym_chars[s])
+                    plen += int(q[2]) >> 26
+                    goff = int(q[2]) & 0x03FFFFFF
+                    goff = NONE if goff == 0x03FFFFFF else goff
+                else:
+                    plen += int(self.sym_chars[s])
+                    goff = int(q[2])
+                gbits = (meta >> 24) & 31
                 if plen >= max_len:
                     restart = True
             if restart:

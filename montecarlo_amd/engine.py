@@ -412,6 +412,8 @@ def device_query_guess_numbers(rk: "DeviceRank", x: torch.Tensor, add1: bool = T
                                exact: torch.Tensor = None):
     """rk.query(x) and device_guess_numbers in one call (mc_rank_runs_guess_numbers: two launches, not three) when
     ``rk`` holds a run index; otherwise the two calls.  -> (pos, cnt, ranks, exact)."""
+    _require_gpu()
+    assert x.is_cuda and x.dtype == torch.float64 and x.is_contiguous()
     t = x.numel()
     dev = x.device
     with torch.cuda.device(dev):

@@ -571,7 +571,7 @@ int mc_order_keys(const double *x, uint64_t t, double *x_sorted, uint32_t *order
                   size_t workspace_bytes, void *stream);
 /* The loop of ml2p_iter2gc (lib4mc/MonteCarloLib.py:47-55) over t passwords IN ASCENDING ORDER of -log2 p:
  * estimate_i = pos[i] if cnt[i] > 0 else 1 (cnt == NULL: pos[i] > 0 decides, the sharded form where only the
- * summed positions travel), rank_i = ceil(max(estimate_i, rank_{i-1} + (1 if add1 else 0))), rank_0 = 0.
+ * summed positions travel; a NaN position -- a failed index, on any shard -- stays NaN and ends the exact prefix), rank_i = ceil(max(estimate_i, rank_{i-1} + (1 if add1 else 0))), rank_0 = 0.
  * pos / cnt are what mc_rank_query returned (summed over shards).  out_rank[t] (device int64) is exact for the
  * first *out_exact passwords (device uint64, written by the call): the reference computes in Python integers and
  * guess numbers are not bounded by 2^63; estimates ascend, so what does not fit (ceil(estimate) >= 2^62, or a

@@ -16,8 +16,9 @@
 //   k_rl_sniff   one workgroup: a 16384-key sample gives the values that repeat often ("heavy", <= 1024, ascending)
 //                and the range [lo, hi] the other keys spread over.  The list and the range of the last build of n
 //                keys in the same workspace are taken again while they still fit (any list and any range give a
-//                correct index; stale ones only cost time).
-//   k_rl_strip   ONE read of all keys.  A copy of a heavy value is counted in LDS.  Every other key ("tail") goes to
+//                correct index; stale ones only cost time).  The heavy values are also laid out as a two-choice
+//                hash table (each in one of its two slots) that k_rl_strip copies into LDS.
+//   k_rl_strip   ONE read of all keys.  A copy of a heavy value is counted in LDS (two reads of the table, no walk).  Every other key ("tail") goes to
 //                an LDS buffer; a full buffer (4096 keys, a "batch") is ordered by BIN -- bin = floor((key - lo) *
 //                P / (hi - lo)), clamped: monotone in the key -- and written out with the offsets of its P + 1 bin
 //                borders.  No global atomics per key, nothing another workgroup has to wait for.
@@ -92,6 +93,8 @@ struct RWs {
     RCtl *ctl;
     u64 *heavy;      // [H_MAX] ascending
     u32 *hcnt;       // [H_MAX] their copies
+    u64 *htab;       // [HSET] the heavy values as a two-choice table (k_rl_sniff builds it, k_rl_strip copies it to LDS)
+    u32 *hidx;       // [HSET] slot -> index into `heavy`
     const u64 *in;
     u64 *tail;       // [n] region r's batches at r * region + j * TBUF, each ordered by bin
     u32 *nbatch;     // [regions] batches region r wrote
@@ -195,6 +198,12 @@ __device__ __forceinline__ u32 mix32(u64 k) {
     return x * 0x85EBCA6Bu;
 }
 __device__ __forceinline__ u32 strip_hash(u64 k) { return mix32(k) >> 21; }  // 11 bits = HSET slots
+// the two places a heavy value may have in the strip's table (two-choice hashing: a look-up is two reads, never a walk)
+__device__ __forceinline__ void strip_slots(u64 k, u32 &s1, u32 &s2) {
+    const u32 x = mix32(k);
+    s1 = x >> 21;
+    s2 = (x >> 10) & (u32)(HSET - 1);
+}
 
 // The bin of a key: the range [lo, hi] the sample saw (widened) is cut into CELLS equal cells, and a look-up table
 // made from the sample's own distribution gives every cell its bin, so that the bins hold about equally many keys
@@ -538,6 +547,72 @@ __device__ __forceinline__ void rl_sniff_body(const RWs &w) {
             w.hbin[b] = b == w.P ? H : lo;
         }
     }
+    // ---- the heavy values as a two-choice table for k_rl_strip: every value sits in one of its two slots, so a key
+    //      is looked up with two reads and no walk (a linear-probing table at a fifth full made four keys in a
+    //      hundred walk, which is a branch taken by nearly every wave).  Values take a free slot of theirs at once;
+    //      the few that find both taken are placed one after the other, moving others to their second slots.  A
+    //      value that finds no place after 64 moves is left out: its copies then count as tail keys, which is slower
+    //      and as correct (hcnt stays 0 and k_rl_bins skips it).
+    __syncthreads();
+    if (w.htab) {  // (uniform; the first level of a large build keeps its own table: k_big_strip)
+        static_assert(SNIFF_SLOTS / 2 >= 2 * HSET + HSET, "the table borrows tc");
+        u64 *T = (u64 *)tc;                 // [HSET]   (the histogram that lived here is dead)
+        u32 *I = tc + 2 * HSET;             // [HSET]
+        __shared__ u32 late[64];
+        __shared__ u32 nlate;
+        const u64 *sorted = (const u64 *)tag;
+        for (u32 i = tid; i < (u32)HSET; i += SNIFF_THREADS) {
+            T[i] = EMPTY;
+            I[i] = 0;
+        }
+        if (tid == 0) nlate = 0;
+        __syncthreads();
+        for (u32 i = tid; i < H; i += SNIFF_THREADS) {
+            const u64 v = sorted[i];
+            if (v == EMPTY) continue;
+            u32 s1, s2;
+            strip_slots(v, s1, s2);
+            const u64 o1 = atomicCAS(&T[s1], EMPTY, v);
+            if (o1 == EMPTY) {
+                I[s1] = i;
+            } else if (o1 != v) {
+                const u64 o2 = atomicCAS(&T[s2], EMPTY, v);
+                if (o2 == EMPTY) {
+                    I[s2] = i;
+                } else if (o2 != v) {
+                    const u32 at = atomicAdd(&nlate, 1u);
+                    if (at < 64u) late[at] = i;  // (beyond 64: left out)
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const u32 nl = nlate < 64u ? nlate : 64u;
+            for (u32 j = 0; j < nl; ++j) {
+                u64 cur = sorted[late[j]];
+                u32 curi = late[j];
+                u32 s1, s2;
+                strip_slots(cur, s1, s2);
+                u32 pos = s1;
+                for (int step = 0; step < 64; ++step) {
+                    const u64 ev = T[pos];
+                    const u32 evi = I[pos];
+                    T[pos] = cur;
+                    I[pos] = curi;
+                    if (ev == EMPTY) break;
+                    cur = ev;  // the value that lay there moves to its other slot (left out if the moves run out)
+                    curi = evi;
+                    strip_slots(cur, s1, s2);
+                    pos = pos == s1 ? s2 : s1;
+                }
+            }
+        }
+        __syncthreads();
+        for (u32 i = tid; i < (u32)HSET; i += SNIFF_THREADS) {
+            w.htab[i] = T[i];
+            w.hidx[i] = I[i];
+        }
+    }
 }
 
 // ---- strip: count the copies of heavy values, order the rest by bin ------------------------------------------
@@ -545,8 +620,8 @@ __device__ __forceinline__ void rl_strip_body(const RWs &w) {
     static_assert(HSET == 2048, "strip_hash yields 11 bits");
     static_assert(TBUF == TILE && TBUF == ITEMS * WG, "a batch is flushed by the whole workgroup, ITEMS keys a lane");
     static_assert(P_MAX == 2 * WG, "the scan of the bins' counts takes two bins a thread");
-    __shared__ u64 hk[HSET + 1];   // (+1: the pair read of the last slot)
-    __shared__ u32 hs[HSET + 1];   // copies counted per slot
+    __shared__ u64 hk[HSET];       // the heavy values, each in one of its two slots
+    __shared__ u32 hs[HSET];       // copies counted per slot
     __shared__ u32 hi[HSET];       // slot -> index of the heavy value
     __shared__ u64 tb[TBUF];       // tail keys waiting for their batch
     __shared__ u32 bh[P_MAX + 1];  // keys per bin of the batch, then the bins' offsets
@@ -558,26 +633,13 @@ __device__ __forceinline__ void rl_strip_body(const RWs &w) {
     const u32 H = w.ctl->n_heavy <= (u32)H_MAX ? w.ctl->n_heavy : 0u;
     const u32 n = w.n, P = w.P;
     const BinMap bm = bin_map(w.ctl->map_lo, w.ctl->map_hi, slut);
-    for (u32 i = tid; i <= (u32)HSET; i += WG) {
-        hk[i] = EMPTY;
+    // the table of the heavy values as k_rl_sniff laid it out (two-choice hashing: strip_slots)
+    for (u32 i = tid; i < (u32)HSET; i += WG) {
+        hk[i] = H ? w.htab[i] : EMPTY;
+        hi[i] = H ? w.hidx[i] : 0u;
         hs[i] = 0;
     }
     for (u32 i = tid; i < (u32)CELLS / 2; i += WG) ((u32 *)slut)[i] = ((const u32 *)w.lut)[i];
-    __syncthreads();
-    for (u32 i = tid; i < H; i += WG) {
-        const u64 v = w.heavy[i];
-        if (v == EMPTY) continue;
-        u32 s = strip_hash(v);
-        for (;;) {  // H <= HSET / 2 distinct values
-            const u64 old = atomicCAS(&hk[s], EMPTY, v);
-            if (old == EMPTY) {
-                hi[s] = i;
-                break;
-            }
-            if (old == v) break;  // (a list that repeats a value: never ours, but never a hang either)
-            s = (s + 1) & (HSET - 1);
-        }
-    }
     __syncthreads();
     const u64 lt = (1ull << lane) - 1ull;
     u32 tail_total = 0, allones = 0;  // (thread 0 / every thread)
@@ -655,45 +717,26 @@ __device__ __forceinline__ void rl_strip_body(const RWs &w) {
                     nk[q] = w.in[lo + (j < rn ? j : rn - 1)];
                 }
             }
-            // heavy test without branches: the key's home slot and the next one are read together; only a key that
-            // meets two other values there walks on (rare: the table is at most half full)
+            // heavy or not: a key's two slots are read together; it is heavy if one of them holds it (no walk)
             u64 tmask[ITEMS];
             u32 total = 0;
             {
-                u32 s[ITEMS];
+                u32 s1[ITEMS], s2[ITEMS];
                 u64 a[ITEMS], b[ITEMS];
 #pragma unroll
                 for (int q = 0; q < ITEMS; ++q) {
-                    s[q] = strip_hash(k[q]);
-                    a[q] = hk[s[q]];
-                    b[q] = hk[s[q] + 1];  // (slot HSET is a spare that stays empty)
+                    strip_slots(k[q], s1[q], s2[q]);
+                    a[q] = hk[s1[q]];
+                    b[q] = hk[s2[q]];
                 }
 #pragma unroll
                 for (int q = 0; q < ITEMS; ++q) {
                     const bool valid = c0 + q * WG + tid < rn;
-                    const bool real = valid && k[q] != EMPTY;
+                    const bool real = valid && k[q] != EMPTY;  // (a key of all ones matches the table's empty marker: never heavy)
                     if (valid && !real) ++allones;
-                    const bool hit_a = real && a[q] == k[q];
-                    const bool hit_b = real && !hit_a && a[q] != EMPTY && b[q] == k[q];
-                    bool walk = real && !hit_a && !hit_b && a[q] != EMPTY && (b[q] != EMPTY || s[q] + 1 == (u32)HSET);
-                    bool heavy = hit_a || hit_b;
-                    u32 slot = s[q] + (hit_b ? 1u : 0u);
-                    if (__ballot(walk)) {  // (rare)
-                        if (walk) {
-                            u32 t = s[q] + 1 == (u32)HSET ? 0u : (s[q] + 2 == (u32)HSET ? 0u : s[q] + 2);
-                            for (;;) {
-                                const u64 v = hk[t];
-                                if (v == k[q]) {
-                                    heavy = true;
-                                    slot = t;
-                                    break;
-                                }
-                                if (v == EMPTY) break;
-                                t = t + 1 == (u32)HSET ? 0u : t + 1;
-                            }
-                        }
-                    }
-                    if (heavy) atomicAdd(&hs[slot], 1u);
+                    const bool hit_a = a[q] == k[q];
+                    const bool heavy = real && (hit_a || b[q] == k[q]);
+                    if (heavy) atomicAdd(&hs[hit_a ? s1[q] : s2[q]], 1u);
                     tmask[q] = __ballot(real && !heavy);
                     total += (u32)__popcll(tmask[q]);
                 }
@@ -1492,6 +1535,7 @@ __global__ void __launch_bounds__(64) k_big_setup(BWs bw) {
     RWs p = bw.templ;
     const size_t by = (size_t)g * bw.slice;
     move_on(p.ctl, by); move_on(p.heavy, by); move_on(p.hcnt, by); move_on(p.tail, by); move_on(p.nbatch, by);
+    move_on(p.htab, by); move_on(p.hidx, by);
     move_on(p.rmax, by); move_on(p.hbin, by); move_on(p.lut, by); move_on(p.cell0, by); move_on(p.start, by);
     move_on(p.rval, by); move_on(p.rccum, by); move_on(p.rwcum, by); move_on(p.bin_d, by); move_on(p.bin_c, by);
     move_on(p.bin_w, by);
@@ -1695,7 +1739,7 @@ u64 *phase_ptr() {
 }
 
 struct RLayout {
-    size_t ctl, heavy, hcnt, nbatch, rmax, hbin, lut, cell0, bin_d, bin_c, bin_w, start, rval, rccum, rwcum, tail, end;
+    size_t ctl, heavy, hcnt, htab, hidx, nbatch, rmax, hbin, lut, cell0, bin_d, bin_c, bin_w, start, rval, rccum, rwcum, tail, end;
     u32 region, regions, nb, P;
 };
 
@@ -1714,6 +1758,8 @@ RLayout layout_for(u64 n, u32 force_P = 0) {
     L.ctl = p; p += align256(sizeof(RCtl));
     L.heavy = p; p += align256(H_MAX * sizeof(u64));
     L.hcnt = p; p += align256(H_MAX * sizeof(u32));
+    L.htab = p; p += align256(HSET * sizeof(u64));
+    L.hidx = p; p += align256(HSET * sizeof(u32));
     L.nbatch = p; p += align256((size_t)L.regions * sizeof(u32));
     L.rmax = p; p += align256((size_t)L.regions * sizeof(u64));
     L.hbin = p; p += align256((P_MAX + 1) * sizeof(u32));
@@ -1805,6 +1851,8 @@ int build_big(const double *keys_in, uint64_t n, uint64_t n_global, double *vals
     w.ctl = (RCtl *)(g0 + L.ctl);
     w.heavy = (u64 *)(g0 + L.heavy);
     w.hcnt = (u32 *)(g0 + L.hcnt);
+    w.htab = (u64 *)(g0 + L.htab);
+    w.hidx = (u32 *)(g0 + L.hidx);
     w.tail = (u64 *)(g0 + L.tail);
     w.nbatch = (u32 *)(g0 + L.nbatch);
     w.rmax = (u64 *)(g0 + L.rmax);
@@ -1911,6 +1959,8 @@ extern "C" int mc_rank_runs_build(const double *keys_in, uint64_t n, uint64_t n_
     w.ctl = (RCtl *)(base + L.ctl);
     w.heavy = (u64 *)(base + L.heavy);
     w.hcnt = (u32 *)(base + L.hcnt);
+    w.htab = (u64 *)(base + L.htab);
+    w.hidx = (u32 *)(base + L.hidx);
     w.in = (const u64 *)keys_in;
     w.tail = (u64 *)(base + L.tail);
     w.nbatch = (u32 *)(base + L.nbatch);

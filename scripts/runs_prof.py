@@ -37,5 +37,5 @@ if os.environ.get("RUNS_PHASES"):
     r.build(keys)
     nv.check(nv.lib.mc_rank_runs_debug_phases(0, ph))
     ph = list(ph)
-    print("phase ticks (100 MHz, summed over workgroups):", ph[:8], "longest workgroup", ph[14],
+    print("phase ticks (100 MHz, summed over workgroups):", ph[:13], "longest workgroup", ph[14],
           "first start to last end", ph[15] - ((~ph[13]) & 0xFFFFFFFFFFFFFFFF) if ph[13] else None)

@@ -41,7 +41,7 @@ os.environ.setdefault("TQDM_DISABLE", "1")
 from montecarlo_amd import synth  # noqa: E402
 from montecarlo_amd.backwords_simulator import BackWordsMonteCarlo  # noqa: E402
 from montecarlo_amd.engine import (DeviceRank, RunsBuffers, device_guess_numbers, device_order,  # noqa: E402
-                                  device_query_guess_numbers)
+                                  device_order_begin, device_order_end, device_query_guess_numbers)
 from montecarlo_amd import _native as nv  # noqa: E402
 from montecarlo_amd import dist as mcd  # noqa: E402
 
@@ -184,6 +184,10 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the legs after the timed region that run BASELINE configs 3, 4, 5 and the sub-word "
                          "scorer once at their per-GPU sizes (`other_configs` in the JSON line; about a minute)")
+    ap.add_argument("--whole-order", action="store_true",
+                    help="the main stream waits for the whole stable order of the test set (mc_order_keys) before its "
+                         "queries; by default it waits for the sorted scores only (mc_order_keys_begin) and the "
+                         "passwords' order is finished beside the queries (mc_order_keys_end)")
     ap.add_argument("--no-fused-query", action="store_true",
                     help="one GPU, run index: answer the queries in a launch of their own (mc_rank_runs_query + "
                          "mc_guess_numbers, three launches) instead of inside the guess numbers' first kernel")
@@ -245,6 +249,7 @@ def main():
     # when it is about to write the same set again, two steps later
     q_pos = [torch.empty(T, dtype=torch.float64, device=dev) for _ in range(2)]
     t_sorted = [torch.empty(T, dtype=torch.float64, device=dev) for _ in range(2)]
+    t_vals = [torch.empty(T, dtype=torch.float64, device=dev) for _ in range(2)]     # (mc_order_keys_begin: the scores ascending, as numbers)
     t_order = [torch.empty(T, dtype=torch.int32, device=dev) for _ in range(2)]
     # (the guess numbers and the count of those that are exact share one buffer: ONE copy to the host a step)
     # (T + 1 words rounded up to whole 16 bytes: mc_sample_carry moves 16-byte words)
@@ -259,6 +264,7 @@ def main():
     ws_order = torch.empty(nv.lib.mc_order_workspace_bytes(T), dtype=torch.uint8, device=dev)
     ws_gn = torch.empty(nv.lib.mc_guess_numbers_workspace_bytes(T), dtype=torch.uint8, device=dev)
     reduced, copied, copied_on = [None, None], [None, None], [None, None]
+    order_done = [None, None]                               # (second stream: when a set's order of the passwords is whole)
     comm = torch.cuda.Stream(device=dev) if world > 1 and args.overlap_comm else None
     copy = torch.cuda.Stream(device=dev)
     q_cnt = torch.empty(T, dtype=torch.int64, device=dev)
@@ -286,11 +292,16 @@ def main():
         second stream from the start of the step unless --serial; the guess numbers reach the host with the
         next step's sampling launch (--d2h)."""
         if timed:
-            marks = [torch.cuda.Event(enable_timing=True) for _ in range(12)]
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(13)]
         else:                                                # (only what orders the streams)
-            marks = [torch.cuda.Event() if i in (0, 6, 8, 11) else _NoMark for i in range(12)]
+            marks = [torch.cuda.Event() if i in (0, 6, 8, 11, 12) else _NoMark for i in range(13)]
         slot = it & 1
         first = first_id(it, world, rank, N)                # disjoint Philox sample ids per rank and step
+        if side is not None and not args.whole_order and order_done[slot ^ 1] is not None:
+            # a step's results are whole before the next one samples (and the order's last launches do not sit beside
+            # the sampler, which they slow: 0.651 ms a step without this wait, 0.648 with it)
+            main_stream.wait_event(order_done[slot ^ 1])
+            order_done[slot ^ 1] = None
         marks[0].record()
         if side is not None:
             # the test set's scores and their order do not depend on the samples: a second stream computes them
@@ -303,8 +314,18 @@ def main():
                 marks[3].record()
                 dm.score_device(d_syms, d_off, T, out=t_ml2p)
                 marks[4].record()
-                device_order(t_ml2p, out_sorted=t_sorted[slot], out_order=t_order[slot], workspace=ws_order)
-                marks[6].record()
+                if args.whole_order:
+                    device_order(t_ml2p, out_sorted=t_sorted[slot], out_order=t_order[slot], workspace=ws_order)
+                    marks[6].record()
+                    marks[12] = marks[6]
+                else:
+                    # the queries need the scores in ascending order, not which password has which: the main stream
+                    # waits for the key sort (marks[6]) and the passwords' order is finished beside its queries
+                    device_order_begin(t_ml2p, t_sorted[slot], t_vals[slot], ws_order)
+                    marks[6].record()
+                    device_order_end(t_ml2p, t_sorted[slot], t_order[slot], ws_order)
+                    marks[12].record()
+                order_done[slot] = marks[12]
         if carry_mode and pending[0] is not None:
             dm.sample(N, seed, first_id=first, out=keys, carry=(g_both[pending[0]], h_both[pending[0]]))
             pending[0] = None
@@ -332,20 +353,22 @@ def main():
             device_order(t_ml2p, out_sorted=t_sorted[slot], out_order=t_order[slot], workspace=ws_order)
             marks[6].record()
             marks[5] = marks[6]
+            marks[12] = marks[6]
         else:
             main_stream.wait_event(marks[6])
             marks[5].record()
         fused = world == 1 and rk.runs is not None and not args.no_fused_query
+        t_query = t_vals[slot] if (side is not None and not args.whole_order) else t_sorted[slot]
         if fused:
             # one GPU, run index: the bisection inside the guess numbers' first kernel (mc_rank_runs_guess_numbers:
             # two launches where query + guess numbers are three); timed as one stage, under `guess_numbers`
             marks[7] = marks[5]
-            device_query_guess_numbers(rk, t_sorted[slot], True, out_pos=q_pos[slot], out_cnt=q_cnt, out=g_rank[slot],
+            device_query_guess_numbers(rk, t_query, True, out_pos=q_pos[slot], out_cnt=q_cnt, out=g_rank[slot],
                                        workspace=ws_gn, exact=g_exact[slot])
             marks[8].record()
             ready = marks[8]
         else:
-            rk.query(t_sorted[slot], out_pos=q_pos[slot], out_cnt=q_cnt)
+            rk.query(t_query, out_pos=q_pos[slot], out_cnt=q_cnt)
             marks[7].record()
         if fused:
             pass
@@ -387,10 +410,12 @@ def main():
         if carry_mode:
             pending[0] = slot                               # (travels with the next step's sampling launch)
             if args.d2h_all:
+                if side is not None and order_done[slot] is not None:
+                    main_stream.wait_event(order_done[slot])
                 host[slot]["order"].copy_(t_order[slot], non_blocking=True)
                 host[slot]["ml2p"].copy_(t_sorted[slot], non_blocking=True)
             if timed:
-                for k, (a_, b_) in (("sample", (0, 1)), ("rank", (1, 2)), ("score", (3, 4)), ("order", (4, 6)),
+                for k, (a_, b_) in (("sample", (0, 1)), ("rank", (1, 2)), ("score", (3, 4)), ("order", (4, 12)),
                                     ("query", (5, 7))):
                     ev[k].append((marks[a_], marks[b_]))
                 ev["guess_numbers"].append((marks[7] if world == 1 else marks[9], marks[8]))
@@ -408,6 +433,8 @@ def main():
             # once per test set, here after the timed region for the checks (--d2h-all copies them every step)
             h_both[slot].copy_(g_both[slot], non_blocking=True)
             if args.d2h_all:
+                if side is not None and order_done[slot] is not None:
+                    lane.wait_event(order_done[slot])
                 host[slot]["order"].copy_(t_order[slot], non_blocking=True)
                 host[slot]["ml2p"].copy_(t_sorted[slot], non_blocking=True)
             marks[11].record()
@@ -416,7 +443,7 @@ def main():
             ev["sample"].append((marks[0], marks[1]))
             ev["rank"].append((marks[1], marks[2]))
             ev["score"].append((marks[3], marks[4]))
-            ev["order"].append((marks[4], marks[6]))
+            ev["order"].append((marks[4], marks[12]))
             ev["query"].append((marks[5], marks[7]))
             ev["guess_numbers"].append((marks[7] if world == 1 else marks[9], marks[8]))
             ev["d2h"].append((marks[10], marks[11]))
@@ -554,6 +581,9 @@ def main():
             # (one GPU + run index: the queries are answered inside the guess numbers' first kernel; stage `query` is 0
             # and `guess_numbers` holds both)
             "query_inside_guess_numbers": world == 1 and runs_buf is not None and not args.no_fused_query,
+            "queries_wait_for": ("the whole order of the test set (mc_order_keys)" if (args.serial or args.whole_order)
+                                 else "the sorted scores (mc_order_keys_begin); the passwords' order is finished beside them "
+                                      "(mc_order_keys_end, inside the step: `order` in stage_ms spans both)"),
             # one step alone and waited for: the first of the process (code objects load, allocator warms up) and one
             # after the timed region with every workspace's hint forgotten (what ONE estimate costs a caller)
             "first_step_ms": first_step_ms, "cold_step_ms": cold_step_ms,

@@ -569,6 +569,17 @@ void mc_comm_destroy(mc_comm *c);
 size_t mc_order_workspace_bytes(uint64_t t);
 int mc_order_keys(const double *x, uint64_t t, double *x_sorted, uint32_t *order, void *workspace,
                   size_t workspace_bytes, void *stream);
+/* The same sort in two halves (lib4mc/MonteCarloParent.py:68 again: mc_order_keys IS the two calls in a row).  The
+ * bisection of ml2p_iter2gc needs the scores in ascending order, not which password has which: mc_order_keys_begin
+ * runs the key sort and leaves x_values[t] = the scores in ascending order AS NUMBERS (both zeros as +0.0; NaN
+ * everywhere if the key sort gave up; may be NULL), so a caller can put its queries (mc_rank_runs_guess_numbers,
+ * mc_rank_query) on one stream while mc_order_keys_end finishes the passwords' order on another.  Same x, t, x_sorted
+ * and workspace in both; x_sorted holds the sort's own words in between and the caller's bits, as after mc_order_keys,
+ * once mc_order_keys_end has run; x_values is a buffer of its own. */
+int mc_order_keys_begin(const double *x, uint64_t t, double *x_sorted, double *x_values, void *workspace,
+                        size_t workspace_bytes, void *stream);
+int mc_order_keys_end(const double *x, uint64_t t, double *x_sorted, uint32_t *order, void *workspace,
+                      size_t workspace_bytes, void *stream);
 /* The loop of ml2p_iter2gc (lib4mc/MonteCarloLib.py:47-55) over t passwords IN ASCENDING ORDER of -log2 p:
  * estimate_i = pos[i] if cnt[i] > 0 else 1 (cnt == NULL: pos[i] > 0 decides, the sharded form where only the
  * summed positions travel; a NaN position -- a failed index, on any shard -- stays NaN and ends the exact prefix), rank_i = ceil(max(estimate_i, rank_{i-1} + (1 if add1 else 0))), rank_0 = 0.

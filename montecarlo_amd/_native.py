@@ -126,6 +126,8 @@ def _load() -> C.CDLL:
         "mc_rank_build_noalloc": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, vp, vp]),
         "mc_order_workspace_bytes": (C.c_size_t, [C.c_uint64]),
         "mc_order_keys": (C.c_int, [vp, C.c_uint64, vp, vp, vp, C.c_size_t, vp]),
+        "mc_order_keys_begin": (C.c_int, [vp, C.c_uint64, vp, vp, vp, C.c_size_t, vp]),
+        "mc_order_keys_end": (C.c_int, [vp, C.c_uint64, vp, vp, vp, C.c_size_t, vp]),
         "mc_guess_numbers_workspace_bytes": (C.c_size_t, [C.c_uint64]),
         "mc_guess_numbers": (C.c_int, [vp, vp, C.c_uint64, C.c_int, vp, vp, vp, C.c_size_t, vp]),
         "mc_comm_unique_id": (C.c_int, [vp]),
@@ -195,7 +197,7 @@ lib = _load()
 EXPORTS = ["mc_abi_version", "mc_last_error", "mc_table_compile", "mc_table_free", "mc_table_array", "mc_table_info",
            "mc_ctx_hash", "mc_text_hash", "mc_score_words_workspace_bytes", "mc_score_words", "mc_score_bpe", "mc_train_nwords", "mc_train_backwords", "mc_train_v2", "mc_trained_free", "mc_counts_new", "mc_counts_free",
            "mc_counts_merge", "mc_counts_train", "mc_counts_import", "mc_counts_array", "mc_trained_array", "mc_trained_compile", "mc_lines_ingest", "mc_lines_free", "mc_lines_array", "mc_format_gc", "mc_format_gc_cps", "mc_model_upload", "mc_model_destroy", "mc_model_check", "mc_sample", "mc_sample_carry", "mc_sample_tune", "mc_sample_injected", "mc_sample_dedup",
-           "mc_score", "mc_rank_workspace_bytes", "mc_rank_build", "mc_rank_check", "mc_rank_debug_fail", "mc_rank_debug_search", "mc_workspace_forget", "mc_rank_noalloc_max_keys", "mc_rank_build_noalloc", "mc_rank_query", "mc_order_workspace_bytes", "mc_order_keys", "mc_guess_numbers_workspace_bytes", "mc_guess_numbers", "mc_comm_unique_id", "mc_comm_init", "mc_allreduce_rank", "mc_comm_destroy", "mc_enumerate", "mc_enum_info", "mc_enum_fetch",
+           "mc_score", "mc_rank_workspace_bytes", "mc_rank_build", "mc_rank_check", "mc_rank_debug_fail", "mc_rank_debug_search", "mc_workspace_forget", "mc_rank_noalloc_max_keys", "mc_rank_build_noalloc", "mc_rank_query", "mc_order_workspace_bytes", "mc_order_keys", "mc_order_keys_begin", "mc_order_keys_end", "mc_guess_numbers_workspace_bytes", "mc_guess_numbers", "mc_comm_unique_id", "mc_comm_init", "mc_allreduce_rank", "mc_comm_destroy", "mc_enumerate", "mc_enum_info", "mc_enum_fetch",
            "mc_enum_free", "mc_rank_runs_workspace_bytes", "mc_rank_runs_capacity", "mc_rank_runs_max_keys", "mc_rank_runs_build",
            "mc_rank_runs_forget", "mc_rank_runs_check", "mc_rank_runs_query", "mc_rank_runs_expand", "mc_rank_runs_debug_phases",
            "mc_score_words_debug_kernel", "mc_score_bpe_debug_kernel",

@@ -48,16 +48,24 @@ __device__ __forceinline__ u64 order_bits(u64 b) { return mc_sort_order_word(b);
 // the sorted array (20 dependent reads from memory per password were most of this kernel's time).
 constexpr int OW_THREADS = 256, OW_LDS = 4096;
 
-template <bool WORDS>  // WORDS: 64-bit words for a second key sort; else only the 32-bit index L, for the LSD passes
+// the fp64 bits an order word stands for (both zeros come back as +0.0)
+__device__ __forceinline__ u64 order_bits_back(u64 w) { return (w >> 63) ? (w & ~(1ull << 63)) : ~w; }
+
+// WORDS: 64-bit words for a second key sort; else only the 32-bit index L, for the LSD passes.  values (or null):
+// the sorted scores as numbers, values[i] = the i-th smallest (NaN everywhere if the key sort gave up) -- what a
+// caller can put its queries with while the order of the passwords is still being finished (mc_order_keys_begin)
+template <bool WORDS>
 __global__ void __launch_bounds__(OW_THREADS) k_order_words(const u64 *__restrict__ sorted, const u64 *__restrict__ x,
                                                             u64 t, u32 stride, u64 *__restrict__ words,
-                                                            const u32 *sort_err, u32 *failed) {
+                                                            const u32 *sort_err, u32 *failed, u64 *__restrict__ values) {
     __shared__ u64 top[OW_LDS];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *failed = *sort_err;  // (the second sort clears the sort's own word)
+    const bool bad = *sort_err != 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *failed = bad ? 1u : 0u;  // (the second sort clears the sort's own word)
     const u32 nt = (u32)((t + stride - 1) / stride);  // <= OW_LDS by the caller's choice of stride
     for (u32 i = threadIdx.x; i < nt; i += OW_THREADS) top[i] = sorted[(u64)i * stride];
     __syncthreads();
     for (u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x; p < t; p += (u64)gridDim.x * blockDim.x) {
+        if (values) values[p] = bad ? 0x7FF8000000000000ull : order_bits_back(sorted[p]);
         const u64 v = order_bits(x[p]);
         // the last staged key below v: the first key >= v lies after it, at most one stride further
         u32 a = 0, b = nt;  // first staged index with top[i] >= v
@@ -476,41 +484,93 @@ extern "C" size_t mc_order_workspace_bytes(uint64_t t) {
     return align256(mc_sort_workspace_bytes(t)) + 2 * align256(t * sizeof(u64)) + 256 + lsd_table_bytes(t);
 }
 
-extern "C" int mc_order_keys(const double *x, uint64_t t, double *x_sorted, uint32_t *order, void *workspace,
-                             size_t workspace_bytes, void *stream) {
-    if (t == 0) return MC_OK;
-    if (!x || !x_sorted || !order || !workspace || (const void *)x == (const void *)x_sorted) {
-        mc_set_error("mc_order_keys: bad argument");
+namespace {
+
+struct OrderPlan {
+    u64 *words, *words_sorted;
+    u32 *failed;
+    size_t sort_bytes;
+    u32 g, gw, stride;
+};
+
+OrderPlan order_plan(uint64_t t, void *workspace) {
+    OrderPlan o;
+    o.sort_bytes = align256(mc_sort_workspace_bytes(t));
+    o.words = (u64 *)((char *)workspace + o.sort_bytes);
+    o.words_sorted = (u64 *)((char *)o.words + align256(t * sizeof(u64)));
+    o.failed = (u32 *)((char *)o.words_sorted + align256(t * sizeof(u64)));
+    o.g = (u32)((t + 255) / 256 < 2048 ? (t + 255) / 256 : 2048);
+    o.stride = (u32)((t + OW_LDS - 1) / OW_LDS) ? (u32)((t + OW_LDS - 1) / OW_LDS) : 1u;  // (t < 2^32)
+    o.gw = (u32)((t + 2047) / 2048 < 512 ? (t + 2047) / 2048 : 512);
+    return o;
+}
+
+int order_args(const char *who, const double *x, uint64_t t, double *x_sorted, void *workspace, size_t workspace_bytes) {
+    if (!x || !x_sorted || !workspace || (const void *)x == (const void *)x_sorted) {
+        mc_set_error("%s: bad argument", who);
         return MC_ERR_ARG;
     }
     if (t >= 0xFFFFFFFFull) {
-        mc_set_error("mc_order_keys: at most 2^32 - 2 keys (got %llu)", (unsigned long long)t);
+        mc_set_error("%s: at most 2^32 - 2 keys (got %llu)", who, (unsigned long long)t);
         return MC_ERR_ARG;
     }
     if (workspace_bytes < mc_order_workspace_bytes(t)) {
-        mc_set_error("mc_order_keys: workspace of %zu bytes, need %zu", workspace_bytes, mc_order_workspace_bytes(t));
+        mc_set_error("%s: workspace of %zu bytes, need %zu", who, workspace_bytes, mc_order_workspace_bytes(t));
         return MC_ERR_WORKSPACE;
     }
-    hipStream_t s = (hipStream_t)stream;
-    const size_t sort_bytes = align256(mc_sort_workspace_bytes(t));
-    u64 *words = (u64 *)((char *)workspace + sort_bytes);
-    u64 *words_sorted = (u64 *)((char *)words + align256(t * sizeof(u64)));
-    u32 *failed = (u32 *)((char *)words_sorted + align256(t * sizeof(u64)));
-    uint32_t *err1 = nullptr, *err2 = nullptr;
-    const u32 g = (u32)((t + 255) / 256 < 2048 ? (t + 255) / 256 : 2048);
-    // (the sort reads the scores as they are and maps them to order words on the way: no pass of our own for that)
-    int rc = mc_sort_keys((const uint64_t *)x, t, (uint64_t *)x_sorted, workspace, sort_bytes, &err1, MC_SORT_RAW_F64, s);
+    return MC_OK;
+}
+
+}  // namespace
+
+// The first half of mc_order_keys: the key sort and, per password, the index of the first sorted key equal to its
+// own.  x_values (or null) receives the scores in ascending order AS NUMBERS (both zeros as +0.0): all that the
+// bisection needs, so a caller may put its queries while mc_order_keys_end is still finishing the order of the
+// passwords on another stream.  x_sorted holds the sort's order words until mc_order_keys_end has run.
+extern "C" int mc_order_keys_begin(const double *x, uint64_t t, double *x_sorted, double *x_values, void *workspace,
+                                   size_t workspace_bytes, void *stream) {
+    if (t == 0) return MC_OK;
+    int rc = order_args("mc_order_keys_begin", x, t, x_sorted, workspace, workspace_bytes);
     if (rc != MC_OK) return rc;
-    const u32 stride = (u32)((t + OW_LDS - 1) / OW_LDS) ? (u32)((t + OW_LDS - 1) / OW_LDS) : 1u;  // (t < 2^32)
-    const u32 gw = (u32)((t + 2047) / 2048 < 512 ? (t + 2047) / 2048 : 512);
+    if ((const void *)x_values == (const void *)x || (const void *)x_values == (const void *)x_sorted) {
+        mc_set_error("mc_order_keys_begin: x_values must be a buffer of its own");
+        return MC_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const OrderPlan o = order_plan(t, workspace);
+    uint32_t *err1 = nullptr;
+    // (the sort reads the scores as they are and maps them to order words on the way: no pass of our own for that)
+    rc = mc_sort_keys((const uint64_t *)x, t, (uint64_t *)x_sorted, workspace, o.sort_bytes, &err1, MC_SORT_RAW_F64, s);
+    if (rc != MC_OK) return rc;
+    if (t <= LS_MAX_T)
+        hipLaunchKernelGGL(k_order_words<false>, dim3(o.gw), dim3(OW_THREADS), 0, s, (const u64 *)x_sorted, (const u64 *)x,
+                           (u64)t, o.stride, o.words, (const u32 *)err1, o.failed, (u64 *)x_values);
+    else
+        hipLaunchKernelGGL(k_order_words<true>, dim3(o.gw), dim3(OW_THREADS), 0, s, (const u64 *)x_sorted, (const u64 *)x,
+                           (u64)t, o.stride, o.words, (const u32 *)err1, o.failed, (u64 *)x_values);
+    HIP_TRY(hipGetLastError());
+    return MC_OK;
+}
+
+// The second half: the passwords' stable order from what mc_order_keys_begin left in the workspace (same x, t,
+// x_sorted and workspace), and x_sorted as the caller's own bits.
+extern "C" int mc_order_keys_end(const double *x, uint64_t t, double *x_sorted, uint32_t *order, void *workspace,
+                                 size_t workspace_bytes, void *stream) {
+    if (t == 0) return MC_OK;
+    int rc = order_args("mc_order_keys_end", x, t, x_sorted, workspace, workspace_bytes);
+    if (rc != MC_OK) return rc;
+    if (!order) {
+        mc_set_error("mc_order_keys_end: bad argument");
+        return MC_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const OrderPlan o = order_plan(t, workspace);
     if (t <= LS_MAX_T) {
         // (L, index) pairs through stable LSD passes; the buffers of the words hold two u32 arrays each, the
         // digit tables have a region of their own (lsd_table_bytes)
-        u32 *ka = (u32 *)words, *pa = ka + t, *kb = (u32 *)words_sorted, *pb = kb + t;
+        u32 *ka = (u32 *)o.words, *pa = ka + t, *kb = (u32 *)o.words_sorted, *pb = kb + t;
         const u32 tiles = (u32)((t + LS_TILE - 1) / LS_TILE);
-        u32 *table = (u32 *)((char *)failed + 256), *totals = table + (size_t)256 * tiles;
-        hipLaunchKernelGGL(k_order_words<false>, dim3(gw), dim3(OW_THREADS), 0, s, (const u64 *)x_sorted, (const u64 *)x,
-                           (u64)t, stride, words, (const u32 *)err1, failed);
+        u32 *table = (u32 *)((char *)o.failed + 256), *totals = table + (size_t)256 * tiles;
         int nbits = 1;
         while (nbits < 32 && (t - 1) >> nbits) ++nbits;
         const int passes = (nbits + 7) / 8, width = (nbits + passes - 1) / passes;
@@ -525,20 +585,31 @@ extern "C" int mc_order_keys(const double *x, uint64_t t, double *x_sorted, uint
             kin = kout;
             pin = pout;
         }
-        hipLaunchKernelGGL(k_order_out32, dim3(g), dim3(256), 0, s, pin, (const u64 *)x, (u64)t, order, (u64 *)x_sorted,
-                           (const u32 *)failed);
+        hipLaunchKernelGGL(k_order_out32, dim3(o.g), dim3(256), 0, s, pin, (const u64 *)x, (u64)t, order, (u64 *)x_sorted,
+                           (const u32 *)o.failed);
         HIP_TRY(hipGetLastError());
         return MC_OK;
     }
-    hipLaunchKernelGGL(k_order_words<true>, dim3(gw), dim3(OW_THREADS), 0, s, (const u64 *)x_sorted, (const u64 *)x,
-                       (u64)t, stride, words, (const u32 *)err1, failed);
-    rc = mc_sort_keys((const uint64_t *)words, t, (uint64_t *)words_sorted, workspace, sort_bytes, &err2,
+    uint32_t *err2 = nullptr;
+    rc = mc_sort_keys((const uint64_t *)o.words, t, (uint64_t *)o.words_sorted, workspace, o.sort_bytes, &err2,
                       MC_SORT_FEW_REPEATS /* the words are distinct */, s);
     if (rc != MC_OK) return rc;
-    hipLaunchKernelGGL(k_order_out, dim3(g), dim3(256), 0, s, (const u64 *)words_sorted, (const u64 *)x, (u64)t, order,
-                       (u64 *)x_sorted, (const u32 *)err2, (const u32 *)failed);
+    hipLaunchKernelGGL(k_order_out, dim3(o.g), dim3(256), 0, s, (const u64 *)o.words_sorted, (const u64 *)x, (u64)t, order,
+                       (u64 *)x_sorted, (const u32 *)err2, (const u32 *)o.failed);
     HIP_TRY(hipGetLastError());
     return MC_OK;
+}
+
+extern "C" int mc_order_keys(const double *x, uint64_t t, double *x_sorted, uint32_t *order, void *workspace,
+                             size_t workspace_bytes, void *stream) {
+    if (t == 0) return MC_OK;
+    if (!order) {
+        mc_set_error("mc_order_keys: bad argument");
+        return MC_ERR_ARG;
+    }
+    const int rc = mc_order_keys_begin(x, t, x_sorted, nullptr, workspace, workspace_bytes, stream);
+    if (rc != MC_OK) return rc;
+    return mc_order_keys_end(x, t, x_sorted, order, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t mc_guess_numbers_workspace_bytes(uint64_t t) {

@@ -407,6 +407,32 @@ def device_order(x: torch.Tensor, out_sorted: torch.Tensor = None, out_order: to
     return srt, order
 
 
+def device_order_begin(x: torch.Tensor, out_sorted: torch.Tensor, out_values: torch.Tensor, workspace: torch.Tensor):
+    """The first half of device_order (mc_order_keys_begin): the key sort; ``out_values`` receives the scores in
+    ascending order as numbers -- all a bisection needs -- while ``out_sorted`` and the order wait for
+    device_order_end (same tensors, same workspace; typically on another stream than the queries)."""
+    _require_gpu()
+    assert x.is_cuda and x.dtype == torch.float64 and x.is_contiguous()
+    assert out_values.dtype == torch.float64 and out_values.numel() == x.numel() and out_values.is_contiguous()
+    with torch.cuda.device(x.device):
+        if x.numel():
+            nv.check(nv.lib.mc_order_keys_begin(_vp(x), x.numel(), _vp(out_sorted), _vp(out_values), _vp(workspace),
+                                                workspace.numel(),
+                                                C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+    return out_values
+
+
+def device_order_end(x: torch.Tensor, out_sorted: torch.Tensor, out_order: torch.Tensor, workspace: torch.Tensor):
+    """The second half (mc_order_keys_end): the passwords' stable order and the sorted scores as the caller's bits."""
+    _require_gpu()
+    with torch.cuda.device(x.device):
+        if x.numel():
+            nv.check(nv.lib.mc_order_keys_end(_vp(x), x.numel(), _vp(out_sorted), _vp(out_order), _vp(workspace),
+                                              workspace.numel(),
+                                              C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+    return out_sorted, out_order
+
+
 def device_query_guess_numbers(rk: "DeviceRank", x: torch.Tensor, add1: bool = True, out_pos: torch.Tensor = None,
                                out_cnt: torch.Tensor = None, out: torch.Tensor = None, workspace: torch.Tensor = None,
                                exact: torch.Tensor = None):

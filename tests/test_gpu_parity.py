@@ -535,6 +535,47 @@ def test_order_keys_places_groups_of_every_size():
         assert torch.equal(order.long() & 0xFFFFFFFF, want[1]) and torch.equal(srt, want[0])
 
 
+def test_order_in_two_halves_equals_the_whole():
+    """mc_order_keys_begin + mc_order_keys_end == mc_order_keys (same sorted bits, same order), and what the first
+    half leaves for the queries -- the scores ascending as numbers -- equals the sorted scores numerically (-0.0
+    comes back as 0.0: the same number to a bisection), also when the halves run on two streams."""
+    from montecarlo_amd import _native as nv
+    from montecarlo_amd.engine import device_order, device_order_begin, device_order_end
+    rng = np.random.default_rng(5)
+    cases = {
+        "scores": np.round(rng.random(400000) * 60, 2),
+        "zeros and signs": np.concatenate([np.where(rng.random(3000) < 0.5, -0.0, 0.0), rng.standard_normal(5000), [np.inf, 1022.0]]),
+        "few": np.array([2.0, 1.0, 2.0]),
+        "above 2^24": None,
+    }
+    for name, x in cases.items():
+        if x is None:
+            g = torch.Generator().manual_seed(8)
+            xd = (torch.randint(0, 1_000_000, (16_800_000,), generator=g).double() * 2.0 ** -8).cuda()
+        else:
+            xd = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).cuda()
+        t = xd.numel()
+        want_sorted, want_order = device_order(xd)
+        ws = torch.empty(nv.lib.mc_order_workspace_bytes(t), dtype=torch.uint8, device="cuda")
+        srt, vals = torch.empty_like(xd), torch.empty_like(xd)
+        order = torch.empty(t, dtype=torch.int32, device="cuda")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            device_order_begin(xd, srt, vals, ws)
+            half = torch.cuda.Event()
+            half.record()
+            device_order_end(xd, srt, order, ws)
+        torch.cuda.current_stream().wait_event(half)
+        seen = vals.clone()                                  # (what a query launched now would read)
+        side.synchronize()
+        torch.cuda.synchronize()
+        assert torch.equal(order, want_order), name
+        assert torch.equal(srt.view(torch.int64), want_sorted.view(torch.int64)), name
+        assert torch.equal(seen, want_sorted) and torch.equal(vals, want_sorted), name        # (numerically: -0.0 == 0.0)
+        assert not bool((vals.view(torch.int64) == -(1 << 63)).any()), name                  # no -0.0 among the values
+
+
 def test_guess_numbers_equal_reference_loop():
     """mc_guess_numbers == the reference's running expression rank = ceil(max(estimate, prev + add))
     (lib4mc/MonteCarloLib.py:47-55) on ascending estimates, across chunk borders, with estimates that do not

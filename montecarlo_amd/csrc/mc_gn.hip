@@ -144,7 +144,13 @@ __global__ void __launch_bounds__(256) k_lsd_scan(u32 *__restrict__ table, u32 t
 __global__ void __launch_bounds__(LS_THREADS) k_lsd_scatter(const u32 *__restrict__ key, const u32 *__restrict__ pay,
                                                             u64 t, u32 shift, u32 mask, int bits, u32 tiles,
                                                             const u32 *__restrict__ table, const u32 *__restrict__ totals,
-                                                            u32 *__restrict__ key_out, u32 *__restrict__ pay_out) {
+                                                            u32 *__restrict__ key_out, u32 *__restrict__ pay_out,
+                                                            const u64 *__restrict__ x, u64 *__restrict__ x_sorted,
+                                                            const u32 *failed) {
+    // (the last pass: x is given, pay_out is the caller's `order` and x_sorted receives the caller's own bits of every
+    // key in that order -- a pass of their own before; a key sort that gave up marks both, as k_order_out32 did)
+    const bool last = x != nullptr;
+    const bool bad = last && *failed != 0;
     __shared__ unsigned short cc[LS_CHUNKS][256];  // elements of each 64-element chunk per digit, then their prefix
     __shared__ u32 gb[256];
     __shared__ u32 wsum[LS_THREADS / 64];
@@ -203,26 +209,10 @@ __global__ void __launch_bounds__(LS_THREADS) k_lsd_scatter(const u32 *__restric
             const u64 at = (u64)gb[d] + cc[r * (LS_THREADS / 64) + wid][d] + rnk[r];
             if (at < t) {  // (always: the histogram counted these same keys)
                 if (key_out) key_out[at] = k[r];
-                pay_out[at] = p[r];
+                pay_out[at] = bad ? 0xFFFFFFFFu : p[r];
+                if (last) x_sorted[at] = bad ? 0x7FF8000000000000ull : x[p[r]];
             }
         }
-    }
-}
-
-// order[i] = the LSD passes' i-th index, x_sorted[i] = the caller's own bits of that password's key
-__global__ void __launch_bounds__(256) k_order_out32(const u32 *__restrict__ idx, const u64 *__restrict__ x, u64 t,
-                                                     u32 *__restrict__ order, u64 *__restrict__ x_sorted,
-                                                     const u32 *failed) {
-    const bool bad = *failed != 0;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < t; i += (u64)gridDim.x * blockDim.x) {
-        if (bad) {  // the key sort gave up: no order at all rather than a wrong one
-            order[i] = 0xFFFFFFFFu;
-            x_sorted[i] = 0x7FF8000000000000ull;
-            continue;
-        }
-        const u32 o = idx[i];
-        order[i] = o;
-        x_sorted[i] = x[o];
     }
 }
 
@@ -576,17 +566,17 @@ extern "C" int mc_order_keys_end(const double *x, uint64_t t, double *x_sorted, 
         const int passes = (nbits + 7) / 8, width = (nbits + passes - 1) / passes;
         const u32 *kin = ka, *pin = nullptr;  // (first pass: the index is the position)
         for (int ps = 0; ps < passes; ++ps) {
-            u32 *kout = (ps & 1) ? ka : kb, *pout = (ps & 1) ? pa : pb;
+            const bool last = ps + 1 == passes;  // (writes the caller's order and sorted scores itself)
+            u32 *kout = (ps & 1) ? ka : kb, *pout = last ? order : ((ps & 1) ? pa : pb);
             const u32 shift = (u32)(ps * width), mask = (1u << width) - 1u;
             hipLaunchKernelGGL(k_lsd_hist, dim3(tiles), dim3(LS_THREADS), 0, s, kin, (u64)t, shift, mask, tiles, table);
             hipLaunchKernelGGL(k_lsd_scan, dim3(256), dim3(256), 0, s, table, tiles, totals);
             hipLaunchKernelGGL(k_lsd_scatter, dim3(tiles), dim3(LS_THREADS), 0, s, kin, pin, (u64)t, shift, mask, width,
-                               tiles, (const u32 *)table, (const u32 *)totals, ps + 1 < passes ? kout : (u32 *)nullptr, pout);
+                               tiles, (const u32 *)table, (const u32 *)totals, last ? (u32 *)nullptr : kout, pout,
+                               last ? (const u64 *)x : (const u64 *)nullptr, (u64 *)x_sorted, (const u32 *)o.failed);
             kin = kout;
             pin = pout;
         }
-        hipLaunchKernelGGL(k_order_out32, dim3(o.g), dim3(256), 0, s, pin, (const u64 *)x, (u64)t, order, (u64 *)x_sorted,
-                           (const u32 *)o.failed);
         HIP_TRY(hipGetLastError());
         return MC_OK;
     }

@@ -47,6 +47,9 @@ __device__ __forceinline__ u64 order_bits(u64 b) { return mc_sort_order_word(b);
 // OW_STRIDE-th sorted key is staged in LDS and searched there, the rest of the search is confined to one stride of
 // the sorted array (20 dependent reads from memory per password were most of this kernel's time).
 constexpr int OW_THREADS = 256, OW_LDS = 4096;
+constexpr int LS_THREADS = 512, LS_ROUNDS = 4, LS_TILE = LS_THREADS * LS_ROUNDS, LS_CHUNKS = LS_TILE / 64;
+constexpr u64 LS_MAX_T = 1ull << 24;
+static_assert(LS_TILE % OW_THREADS == 0, "k_order_words walks the LSD passes' tiles");
 
 // the fp64 bits an order word stands for (both zeros come back as +0.0)
 __device__ __forceinline__ u64 order_bits_back(u64 w) { return (w >> 63) ? (w & ~(1ull << 63)) : ~w; }
@@ -57,29 +60,45 @@ __device__ __forceinline__ u64 order_bits_back(u64 w) { return (w >> 63) ? (w & 
 template <bool WORDS>
 __global__ void __launch_bounds__(OW_THREADS) k_order_words(const u64 *__restrict__ sorted, const u64 *__restrict__ x,
                                                             u64 t, u32 stride, u64 *__restrict__ words,
-                                                            const u32 *sort_err, u32 *failed, u64 *__restrict__ values) {
+                                                            const u32 *sort_err, u32 *failed, u64 *__restrict__ values,
+                                                            u32 *__restrict__ table, u32 tiles, u32 mask0) {
     __shared__ u64 top[OW_LDS];
+    __shared__ u32 h[256];  // (table != null) the tile's digit histogram of the first LSD pass: k_lsd_hist's, for nothing
     const bool bad = *sort_err != 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) *failed = bad ? 1u : 0u;  // (the second sort clears the sort's own word)
     const u32 nt = (u32)((t + stride - 1) / stride);  // <= OW_LDS by the caller's choice of stride
     for (u32 i = threadIdx.x; i < nt; i += OW_THREADS) top[i] = sorted[(u64)i * stride];
     __syncthreads();
-    for (u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x; p < t; p += (u64)gridDim.x * blockDim.x) {
-        if (values) values[p] = bad ? 0x7FF8000000000000ull : order_bits_back(sorted[p]);
-        const u64 v = order_bits(x[p]);
-        // the last staged key below v: the first key >= v lies after it, at most one stride further
-        u32 a = 0, b = nt;  // first staged index with top[i] >= v
-        while (a < b) {
-            const u32 mid = (a + b) >> 1;
-            if (top[mid] < v) a = mid + 1; else b = mid;
+    for (u32 tile = blockIdx.x; tile < tiles; tile += gridDim.x) {  // (the LSD passes' tiles: LS_TILE passwords in index order)
+        if (table) {
+            if (threadIdx.x < 256) h[threadIdx.x] = 0;
+            __syncthreads();
         }
-        u64 lo = a ? (u64)(a - 1) * stride + 1 : 0, hi = (u64)a * stride < t ? (u64)a * stride : t;
-        while (lo < hi) {
-            const u64 mid = (lo + hi) >> 1;
-            if (sorted[mid] < v) lo = mid + 1; else hi = mid;
+#pragma unroll 2
+        for (int r = 0; r < LS_TILE / OW_THREADS; ++r) {
+            const u64 p = (u64)tile * LS_TILE + (u64)r * OW_THREADS + threadIdx.x;
+            if (p >= t) break;
+            if (values) values[p] = bad ? 0x7FF8000000000000ull : order_bits_back(sorted[p]);
+            const u64 v = order_bits(x[p]);
+            // the last staged key below v: the first key >= v lies after it, at most one stride further
+            u32 a = 0, b = nt;  // first staged index with top[i] >= v
+            while (a < b) {
+                const u32 mid = (a + b) >> 1;
+                if (top[mid] < v) a = mid + 1; else b = mid;
+            }
+            u64 lo = a ? (u64)(a - 1) * stride + 1 : 0, hi = (u64)a * stride < t ? (u64)a * stride : t;
+            while (lo < hi) {
+                const u64 mid = (lo + hi) >> 1;
+                if (sorted[mid] < v) lo = mid + 1; else hi = mid;
+            }
+            if (WORDS) words[p] = (lo << 32) | p;
+            else ((u32 *)words)[p] = (u32)lo;
+            if (table) atomicAdd(&h[(u32)lo & mask0], 1u);
         }
-        if (WORDS) words[p] = (lo << 32) | p;
-        else ((u32 *)words)[p] = (u32)lo;
+        if (table) {
+            __syncthreads();
+            if (threadIdx.x < 256) table[(u64)threadIdx.x * tiles + tile] = h[threadIdx.x];  // (its own entry: zeroed by the same thread)
+        }
     }
 }
 
@@ -91,8 +110,6 @@ __global__ void __launch_bounds__(OW_THREADS) k_order_words(const u64 *__restric
 // with one ballot per digit bit; the waves' 64-element chunks of a tile are prefixed in LDS).  A keys-only sort of
 // the words `L << 32 | index` does the same (and still does above 2^24) at three times the cost: it cannot use
 // that the indices arrive in order.
-constexpr int LS_THREADS = 512, LS_ROUNDS = 4, LS_TILE = LS_THREADS * LS_ROUNDS, LS_CHUNKS = LS_TILE / 64;
-constexpr u64 LS_MAX_T = 1ull << 24;
 
 __global__ void __launch_bounds__(LS_THREADS) k_lsd_hist(const u32 *__restrict__ key, u64 t, u32 shift, u32 mask,
                                                          u32 tiles, u32 *__restrict__ table) {
@@ -483,6 +500,14 @@ struct OrderPlan {
     u32 g, gw, stride;
 };
 
+// the LSD passes over the index L < t: how many, and how many bits each
+void lsd_passes(uint64_t t, int &passes, int &width) {
+    int nbits = 1;
+    while (nbits < 32 && (t - 1) >> nbits) ++nbits;
+    passes = (nbits + 7) / 8;
+    width = (nbits + passes - 1) / passes;
+}
+
 OrderPlan order_plan(uint64_t t, void *workspace) {
     OrderPlan o;
     o.sort_bytes = align256(mc_sort_workspace_bytes(t));
@@ -532,12 +557,19 @@ extern "C" int mc_order_keys_begin(const double *x, uint64_t t, double *x_sorted
     // (the sort reads the scores as they are and maps them to order words on the way: no pass of our own for that)
     rc = mc_sort_keys((const uint64_t *)x, t, (uint64_t *)x_sorted, workspace, o.sort_bytes, &err1, MC_SORT_RAW_F64, s);
     if (rc != MC_OK) return rc;
-    if (t <= LS_MAX_T)
+    const u32 tiles = (u32)((t + LS_TILE - 1) / LS_TILE);
+    if (t <= LS_MAX_T) {
+        // (the search walks the LSD passes' tiles and leaves the first pass's digit histograms in their table)
+        int passes, width;
+        lsd_passes(t, passes, width);
+        u32 *table = (u32 *)((char *)o.failed + 256);
         hipLaunchKernelGGL(k_order_words<false>, dim3(o.gw), dim3(OW_THREADS), 0, s, (const u64 *)x_sorted, (const u64 *)x,
-                           (u64)t, o.stride, o.words, (const u32 *)err1, o.failed, (u64 *)x_values);
-    else
+                           (u64)t, o.stride, o.words, (const u32 *)err1, o.failed, (u64 *)x_values, table, tiles,
+                           (1u << width) - 1u);
+    } else {
         hipLaunchKernelGGL(k_order_words<true>, dim3(o.gw), dim3(OW_THREADS), 0, s, (const u64 *)x_sorted, (const u64 *)x,
-                           (u64)t, o.stride, o.words, (const u32 *)err1, o.failed, (u64 *)x_values);
+                           (u64)t, o.stride, o.words, (const u32 *)err1, o.failed, (u64 *)x_values, (u32 *)nullptr, tiles, 0u);
+    }
     HIP_TRY(hipGetLastError());
     return MC_OK;
 }
@@ -561,15 +593,15 @@ extern "C" int mc_order_keys_end(const double *x, uint64_t t, double *x_sorted, 
         u32 *ka = (u32 *)o.words, *pa = ka + t, *kb = (u32 *)o.words_sorted, *pb = kb + t;
         const u32 tiles = (u32)((t + LS_TILE - 1) / LS_TILE);
         u32 *table = (u32 *)((char *)o.failed + 256), *totals = table + (size_t)256 * tiles;
-        int nbits = 1;
-        while (nbits < 32 && (t - 1) >> nbits) ++nbits;
-        const int passes = (nbits + 7) / 8, width = (nbits + passes - 1) / passes;
+        int passes, width;
+        lsd_passes(t, passes, width);
         const u32 *kin = ka, *pin = nullptr;  // (first pass: the index is the position)
         for (int ps = 0; ps < passes; ++ps) {
             const bool last = ps + 1 == passes;  // (writes the caller's order and sorted scores itself)
             u32 *kout = (ps & 1) ? ka : kb, *pout = last ? order : ((ps & 1) ? pa : pb);
             const u32 shift = (u32)(ps * width), mask = (1u << width) - 1u;
-            hipLaunchKernelGGL(k_lsd_hist, dim3(tiles), dim3(LS_THREADS), 0, s, kin, (u64)t, shift, mask, tiles, table);
+            if (ps)  // (the first pass's histograms are mc_order_keys_begin's: its search kernel counted them)
+                hipLaunchKernelGGL(k_lsd_hist, dim3(tiles), dim3(LS_THREADS), 0, s, kin, (u64)t, shift, mask, tiles, table);
             hipLaunchKernelGGL(k_lsd_scan, dim3(256), dim3(256), 0, s, table, tiles, totals);
             hipLaunchKernelGGL(k_lsd_scatter, dim3(tiles), dim3(LS_THREADS), 0, s, kin, pin, (u64)t, shift, mask, width,
                                tiles, (const u32 *)table, (const u32 *)totals, last ? (u32 *)nullptr : kout, pout,

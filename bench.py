@@ -191,9 +191,10 @@ def main():
     ap.add_argument("--no-fused-query", action="store_true",
                     help="one GPU, run index: answer the queries in a launch of their own (mc_rank_runs_query + "
                          "mc_guess_numbers, three launches) instead of inside the guess numbers' first kernel")
-    ap.add_argument("--time-every", type=int, default=1,
+    ap.add_argument("--time-every", type=int, default=0,
                     help="record the stage events (stage_ms, the roofline's kernel_ms) in every K-th timed step only: "
-                         "each recorded event is a host call and a barrier packet on the queue")
+                         "each recorded event is a host call and a barrier packet on the queue (nine of them a step "
+                         "cost 4 us of its 0.64 ms).  Default: every 8th step from 64 timed steps on, else every step")
     ap.add_argument("--dump-last", default="",
                     help="rank 0 writes what the host received from the last timed step (guess numbers, how many of "
                          "them fit int64, order, sorted scores) to this .npz (tests/test_gpu_bench_modes.py)")
@@ -454,6 +455,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    time_every = args.time_every if args.time_every > 0 else (8 if args.steps >= 64 else 1)
     first_step_ms = None
     for w in range(args.warmup):
         if w == 0:                                          # the very first step of the process, alone and waited for
@@ -468,7 +470,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        step(args.warmup + s, s % args.time_every == 0)
+        step(args.warmup + s, s % time_every == 0)
     flush_carry()
     issued = time.perf_counter() - t0                       # the host's share: launching, not waiting
     fence()
@@ -591,6 +593,7 @@ def main():
             "stage_ms_note": ("score and order run on a second stream beside sample and rank (their times include "
                               "waiting for free slots); the step is sample + rank + query + guess_numbers"
                               if side is not None else "one stream: the step is the sum of the stages"),
+            "stage_events_every": time_every,
             "d2h": ("carry: each step's guess numbers travel with the next step's sampling launch (mc_sample_carry), "
                     "the last step's after the loop, inside the timed region" if carry_mode else args.d2h),
             "host_issue_ms_per_step": issued / args.steps * 1e3,

@@ -295,7 +295,8 @@ def main():
         if timed:
             marks = [torch.cuda.Event(enable_timing=True) for _ in range(13)]
         else:                                                # (only what orders the streams)
-            marks = [torch.cuda.Event() if i in (0, 6, 8, 11, 12) else _NoMark for i in range(13)]
+            needed = (0, 6, 12) if carry_mode else (0, 6, 8, 11, 12)      # (what orders the streams and the copies)
+            marks = [torch.cuda.Event() if i in needed else _NoMark for i in range(13)]
         slot = it & 1
         first = first_id(it, world, rank, N)                # disjoint Philox sample ids per rank and step
         if side is not None and not args.whole_order and order_done[slot ^ 1] is not None:

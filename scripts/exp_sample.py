@@ -29,7 +29,7 @@ for i in range(10):
 torch.cuda.synchronize()
 cnt = dm.check()
 ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(10))
-print(json.dumps({"ms_med": ts[5], "ms_min": ts[0], "indirect_per_draw": cnt["indirect_draws"] / cnt["draws"],
+print(json.dumps({"ms_med": ts[5], "ms_min": ts[0], "draws_per_sample": cnt["draws"] / (10 * N), "restarts": cnt.get("restarts"), "indirect_per_draw": cnt["indirect_draws"] / cnt["draws"],
                   "probes_per_draw": cnt["cdf_probes"] / cnt["draws"], "table_mb": m._flat.info[8] / 1e6,
                   "checksum": float(keys.sum())}))
 """ % ROOT

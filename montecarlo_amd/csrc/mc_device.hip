@@ -165,7 +165,10 @@ constexpr unsigned int RING_CHUNKS = 4;   // chunk starts a wave remembers (> RI
 
 // CHARS: how a symbol's length is known -- 0 every symbol is one character, 1 read from sym_chars, 2 carried by the
 // draw record (MC_DRAW_LEN_SHIFT)
-template <bool INJECT, int CHARS, int NC>
+// EXTRAS: the strings, their lengths or their draw counts are wanted (out_syms / out_len / out_draws); without
+// them -- the estimator's own call: scores only -- the kernel carries no state for them (it is bound by the
+// instructions it issues: DESIGN.md 3.1)
+template <bool INJECT, int CHARS, int NC, bool EXTRAS = true>
 __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
     // the head of the draw table (the rows with the most visits per bucket: mc_table.cpp places them
     // first) lives in LDS: a.hot_recs records, loaded once per workgroup
@@ -288,7 +291,7 @@ __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
         local[c] = slot[c] = 0;
         live[c] = claim(true, slot[c], local[c]);
         any |= live[c];
-        sym_row[c] = a.out_syms ? a.out_syms + (b0 + local[c]) * a.sym_stride : nullptr;
+        sym_row[c] = EXTRAS && a.out_syms ? a.out_syms + (b0 + local[c]) * a.sym_stride : nullptr;
         goff[c] = m.start_draw;
         gbits[c] = m.start_gbits;
         plen[c] = nsym[c] = draw[c] = 0;
@@ -327,7 +330,7 @@ __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
         }
         bool fresh[NC];
         double res_ml2p[NC];
-        uint32_t res_len[NC], res_draws[NC];
+        uint32_t res_len[NC] = {}, res_draws[NC] = {};
 #pragma unroll
         for (int c = 0; c < NC; ++c) fresh[c] = false;
 #pragma unroll
@@ -386,15 +389,16 @@ __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
             for (int c = 0; c < NC; ++c) {
                 if (!go[c]) continue;
                 acc[c] += rec_f64(q[c]);
-                ++draw[c];
-                ++c_draws;
+                ++draw[c];  // (counted into c_draws when the string is done: one add a string, not one a draw)
                 bool done = false, ok = false, restart = false;
                 if (q[c].w3 & MC_DRAW_END) {
                     if (plen[c] >= m.min_len) done = ok = true; else restart = true;
                 } else {
                     const uint32_t s = MC_DRAW_SYM(q[c].w3);
-                    if (sym_row[c] && nsym[c] < a.sym_stride) sym_row[c][nsym[c]] = s;
-                    ++nsym[c];
+                    if (EXTRAS) {
+                        if (sym_row[c] && nsym[c] < a.sym_stride) sym_row[c][nsym[c]] = s;
+                        ++nsym[c];
+                    }
                     if (CHARS == 2) {
                         const uint32_t off = q[c].w2 & MC_DRAW_OFF_MASK;
                         plen[c] += q[c].w2 >> MC_DRAW_LEN_SHIFT;
@@ -420,9 +424,12 @@ __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
                 }
                 if (done) {
                     fresh[c] = true;
+                    c_draws += draw[c];
                     res_ml2p[c] = ok ? acc[c] : nan;
-                    res_len[c] = nsym[c];
-                    res_draws[c] = draw[c];
+                    if (EXTRAS) {
+                        res_len[c] = nsym[c];
+                        res_draws[c] = draw[c];
+                    }
                     goff[c] = m.start_draw;
                     gbits[c] = m.start_gbits;
                     acc[c] = 0.0;
@@ -452,8 +459,10 @@ __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
                     const unsigned int full = nblk - first >= LINE_KEYS ? (1u << LINE_KEYS) - 1u : (1u << (nblk - first)) - 1u;
                     whole = ((atomicOr(&rbits[e], bit) | bit) == full);
                 }
-                if (a.out_len) a.out_len[i] = res_len[c];
-                if (a.out_draws) a.out_draws[i] = res_draws[c];
+                if (EXTRAS) {
+                    if (a.out_len) a.out_len[i] = res_len[c];
+                    if (a.out_draws) a.out_draws[i] = res_draws[c];
+                }
             }
             const bool got = claim(fresh[c], slot[c], local[c]);  // (before the ring's answer is waited for)
             unsigned long long wm = __builtin_amdgcn_ballot_w64(whole);
@@ -480,7 +489,7 @@ __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
             }
             if (fresh[c]) {
                 live[c] = got;
-                if (a.out_syms) sym_row[c] = a.out_syms + (b0 + local[c]) * a.sym_stride;
+                if (EXTRAS && a.out_syms) sym_row[c] = a.out_syms + (b0 + local[c]) * a.sym_stride;
             }
             any |= live[c];
         }
@@ -1705,20 +1714,24 @@ static int launch_sample(mc_model *m, bool inject, const SampleArgs &a_in, hipSt
         grid += a.carry_groups;
     }
     dim3 g((unsigned)grid), b(256);
+    const bool extras = a.out_len || a.out_draws || a.out_syms;  // (else the lean kernel: scores only)
     if (inject) {
         if (m->len_in_rec) hipLaunchKernelGGL((k_sample<true, 2, 1>), g, b, lds, s, m->dev, a);
         else if (m->multichar) hipLaunchKernelGGL((k_sample<true, 1, 1>), g, b, lds, s, m->dev, a);
         else hipLaunchKernelGGL((k_sample<true, 0, 1>), g, b, lds, s, m->dev, a);
     } else if (m->len_in_rec) {
         if (nc == 2) hipLaunchKernelGGL((k_sample<false, 2, 2>), g, b, lds, s, m->dev, a);
-        else hipLaunchKernelGGL((k_sample<false, 2, 1>), g, b, lds, s, m->dev, a);
+        else if (extras) hipLaunchKernelGGL((k_sample<false, 2, 1>), g, b, lds, s, m->dev, a);
+        else hipLaunchKernelGGL((k_sample<false, 2, 1, false>), g, b, lds, s, m->dev, a);
     } else if (m->multichar) {
         if (nc == 2) hipLaunchKernelGGL((k_sample<false, 1, 2>), g, b, lds, s, m->dev, a);
-        else hipLaunchKernelGGL((k_sample<false, 1, 1>), g, b, lds, s, m->dev, a);
+        else if (extras) hipLaunchKernelGGL((k_sample<false, 1, 1>), g, b, lds, s, m->dev, a);
+        else hipLaunchKernelGGL((k_sample<false, 1, 1, false>), g, b, lds, s, m->dev, a);
     } else {
         if (nc == 2) hipLaunchKernelGGL((k_sample<false, 0, 2>), g, b, lds, s, m->dev, a);
         else if (nc == 4) hipLaunchKernelGGL((k_sample<false, 0, 4>), g, b, lds, s, m->dev, a);
-        else hipLaunchKernelGGL((k_sample<false, 0, 1>), g, b, lds, s, m->dev, a);
+        else if (extras) hipLaunchKernelGGL((k_sample<false, 0, 1>), g, b, lds, s, m->dev, a);
+        else hipLaunchKernelGGL((k_sample<false, 0, 1, false>), g, b, lds, s, m->dev, a);
     }
     HIP_TRY(hipGetLastError());
     return MC_OK;

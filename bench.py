@@ -274,9 +274,10 @@ def main():
     ev = {k: [] for k in ("sample", "rank", "score", "order", "query", "guess_numbers", "d2h")}
     side = None if args.serial else torch.cuda.Stream(device=dev)
     if side is not None or args.sample_wg_per_cu:
-        # one generation of sampling workgroups that leaves each CU a free slot (scripts/side_compare.sh: 14 a CU
-        # 0.807 ms a step, 12 0.787, 10 0.796, 8 0.812, 7 0.759, 6 0.831)
-        dm.tune(wg_per_cu=args.sample_wg_per_cu or int(os.environ.get("MC_SAMPLE_WG_PER_CU", "7")))
+        # one generation of sampling workgroups (round 2, 63 registers a lane: 14 a CU 0.807 ms a step, 12 0.787, 10 0.796,
+        # 8 0.812, 7 0.759, 6 0.831; with the lean kernel's 56 registers, late round 3: 6 0.675, 7 0.626, 8 0.619, 9 and 10 below)
+        dm.tune(wg_per_cu=args.sample_wg_per_cu or int(os.environ.get("MC_SAMPLE_WG_PER_CU", "8")),
+                skew=float(os.environ.get("MC_SAMPLE_SKEW", "0.65")))  # (ranges' skew beside the second stream: 0.55 0.620 ms a step, 0.65 0.613, 0.75 0.616, 0.85 0.630)
     main_stream = torch.cuda.current_stream(dev)
 
     rk_last = [None]
@@ -301,7 +302,7 @@ def main():
         first = first_id(it, world, rank, N)                # disjoint Philox sample ids per rank and step
         if side is not None and not args.whole_order and order_done[slot ^ 1] is not None:
             # a step's results are whole before the next one samples (and the order's last launches do not sit beside
-            # the sampler, which they slow: 0.651 ms a step without this wait, 0.648 with it)
+            # the sampler, which they slow: 0.622 ms a step without this wait, 0.619 with it)
             main_stream.wait_event(order_done[slot ^ 1])
             order_done[slot ^ 1] = None
         marks[0].record()

@@ -1692,7 +1692,7 @@ static int launch_sample(mc_model *m, bool inject, const SampleArgs &a_in, hipSt
     // (with a copy taken along, 7 a CU -- one generation, the copy workgroups in slots nobody else wants -- take 0.402 ms
     // against 0.420 at 14; without one 0.411 against 0.390)
     const int wg_per_cu = m->tune_wg_per_cu > 0 ? m->tune_wg_per_cu
-                          : (a_in.carry_n16 && !getenv("MC_SAMPLE_WG_PER_CU")) ? 7 : env_wg;
+                          : (a_in.carry_n16 && !getenv("MC_SAMPLE_WG_PER_CU")) ? 8 : env_wg;
     {
         unsigned long long recs = (unsigned long long)(hot_kb < 0 ? 0 : hot_kb > 150 ? 150 : hot_kb) * 1024 / 16;
         a.hot_recs = (uint32_t)(recs < m->n_draw ? recs : m->n_draw);

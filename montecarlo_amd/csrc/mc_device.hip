@@ -306,13 +306,15 @@ __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
 
     while (__builtin_amdgcn_ballot_w64(any) != 0) {  // (the whole wave stays: its lanes write lines out together)
         // ---- two uniforms per chain (draw[c] is even here) ---------------------------------
-        unsigned long long m53[NC][2];
+        // (the 53-bit uniform of a draw is (uh >> 5) << 26 | ul >> 6; its bucket needs the top gbits <= 20 bits only, which
+        // are uh's: the 64-bit value is put together where a threshold is compared, one draw in eighty)
+        uint32_t uh[NC][2], ul[NC][2];
         double rr[NC][2];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const unsigned long long i = b0 + local[c];
             if (INJECT) {
-                m53[c][0] = m53[c][1] = 0;
+                uh[c][0] = uh[c][1] = ul[c][0] = ul[c][1] = 0;
                 rr[c][0] = rr[c][1] = 0.0;
                 if (live[c]) {
                     const double *u = a.uniforms + i * a.max_draws + draw[c];
@@ -323,8 +325,10 @@ __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
                 const unsigned long long sid = a.first_id + i;
                 uint32_t o0, o1, o2, o3;
                 philox4x32_10((uint32_t)sid, (uint32_t)(sid >> 32), draw[c] >> 1, 0u, k0, k1, o0, o1, o2, o3);
-                m53[c][0] = ((unsigned long long)(o0 >> 5) << 26) | (unsigned long long)(o1 >> 6);
-                m53[c][1] = ((unsigned long long)(o2 >> 5) << 26) | (unsigned long long)(o3 >> 6);
+                uh[c][0] = o0;
+                ul[c][0] = o1;
+                uh[c][1] = o2;
+                ul[c][1] = o3;
                 rr[c][0] = rr[c][1] = 0.0;
             }
         }
@@ -350,7 +354,7 @@ __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
                         const uint32_t kmax = (1u << gbits[c]) - 1u;
                         k = kk >= (double)kmax ? kmax : (kk > 0.0 ? (uint32_t)kk : 0u);
                     } else {
-                        k = (uint32_t)(m53[c][h] >> (53u - gbits[c]));
+                        k = (uh[c][h] >> 1) >> (31u - gbits[c]);  // = the uniform >> (53 - gbits), gbits <= 20 (mc_table.cpp)
                     }
                     const uint32_t at = goff[c] + k;
                     if (at < a.hot_recs) q[c] = hot[at]; else q[c] = dtab[at];
@@ -364,7 +368,8 @@ __global__ void __launch_bounds__(256) k_sample(DevModel m, SampleArgs a) {
                 ind[c] = go[c] && type != MC_DRAW_DIRECT;
                 idx[c] = q[c].w2;
                 if (ind[c]) {
-                    const double r = INJECT ? rr[c][h] : (double)m53[c][h] * 0x1.0p-53;
+                    const unsigned long long m53 = ((unsigned long long)(uh[c][h] >> 5) << 26) | (unsigned long long)(ul[c][h] >> 6);
+                    const double r = INJECT ? rr[c][h] : (double)m53 * 0x1.0p-53;
                     if (type == MC_DRAW_ONE) {
                         idx[c] += (r >= rec_f64(q[c])) ? 1u : 0u;
                         ++c_probes;

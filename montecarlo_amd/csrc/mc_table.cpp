@@ -403,7 +403,7 @@ extern "C" int mc_table_compile(const mc_model_desc *d, mc_table **out) {
                 double want = std::max((double)L, lo * std::sqrt(visits[r] * (double)(L - 1)));
                 const uint64_t K = pow2ceil((uint64_t)std::min(want, 1048576.0));
                 while ((1ull << gbits) < K) ++gbits;
-                if (gbits > 20) gbits = 20;
+                if (gbits > 20) gbits = 20;  // (k_sample takes a draw's bucket from the first Philox word of its uniform: <= 27)
             }
             t->state[r].gbits = gbits;
             n_buckets += 1ull << gbits;

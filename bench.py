@@ -629,7 +629,7 @@ def main():
                                    "frac": (bytes_per_launch - (2 * 8 * TB if carry_mode else 0)) / (alone_ms * 1e-3) / 1e9
                                    / HBM_PEAK_GBS,
                                    "what": "50 launches of the same 1e7 samples after the timed region, GPU to itself, "
-                                           "the library's default geometry (14 workgroups a CU), nothing carried"}},
+                                           "the library's default geometry (8 workgroups a CU up to 2^24 samples a launch, 16 beyond), nothing carried"}},
             # the rank build as a whole, timed together: the run index against ONE read of the keys + 24 B per
             # distinct value; the expanded arrays against the 40 B/key a sort-and-scan cannot do without
             "roofline_rank_build": {"bound": "hbm", "kernel": "mc_rank_runs_build (k_rl_sniff, k_rl_strip, k_rl_bins, "

@@ -1690,14 +1690,17 @@ static int launch_sample(mc_model *m, bool inject, const SampleArgs &a_in, hipSt
     // (results never depend on them: tests/test_gpu_parity.py).  Each workgroup's share of the
     // sample ids must fit u32.
     static const int env_nc = getenv("MC_SAMPLE_CHAINS") ? atoi(getenv("MC_SAMPLE_CHAINS")) : 1;
-    static const int env_wg = getenv("MC_SAMPLE_WG_PER_CU") ? atoi(getenv("MC_SAMPLE_WG_PER_CU")) : 14;
+    static const int env_wg = getenv("MC_SAMPLE_WG_PER_CU") ? atoi(getenv("MC_SAMPLE_WG_PER_CU")) : 0;
     static const int env_hot = getenv("MC_SAMPLE_HOT_KB") ? atoi(getenv("MC_SAMPLE_HOT_KB")) : 15;
     const int nc = inject ? 1 : env_nc;
     const int hot_kb = m->tune_hot_kb >= 0 ? m->tune_hot_kb : env_hot;
-    // (with a copy taken along, 7 a CU -- one generation, the copy workgroups in slots nobody else wants -- take 0.402 ms
-    // against 0.420 at 14; without one 0.411 against 0.390)
-    const int wg_per_cu = m->tune_wg_per_cu > 0 ? m->tune_wg_per_cu
-                          : (a_in.carry_n16 && !getenv("MC_SAMPLE_WG_PER_CU")) ? 8 : env_wg;
+    // Workgroups a CU (8 are resident: 56 registers a lane, 19 KB of LDS a workgroup).  ONE generation for a launch of
+    // up to 2^24 samples, two for longer ones, where a second generation takes the slots the first leaves while
+    // its waves thin out (scripts/exp_wg_n.py, late round 3, ms at 8 / 12 / 16 a CU -- headline model: 1e6 samples
+    // 0.085 / 0.106 / 0.118, 1e7 0.364 / 0.400 / 0.378, 3e7 1.03 / 1.09 / 0.97, 1e8 3.23 / 3.41 / 2.89; v2 6-gram: 1e7
+    // 0.262 / 0.300 / 0.274, 1e8 2.37 / 2.25 / 2.25).  With a copy taken along: one generation.
+    const int auto_wg = (a_in.carry_n16 || a.count <= (1ull << 24)) ? 8 : 16;
+    const int wg_per_cu = m->tune_wg_per_cu > 0 ? m->tune_wg_per_cu : env_wg > 0 ? env_wg : auto_wg;
     {
         unsigned long long recs = (unsigned long long)(hot_kb < 0 ? 0 : hot_kb > 150 ? 150 : hot_kb) * 1024 / 16;
         a.hot_recs = (uint32_t)(recs < m->n_draw ? recs : m->n_draw);
@@ -1707,7 +1710,7 @@ static int launch_sample(mc_model *m, bool inject, const SampleArgs &a_in, hipSt
     a.skew = skew < 0.0f ? 0.0f : skew > 0.95f ? 0.95f : skew;
     const size_t lds = (size_t)a.hot_recs * sizeof(DrawRec);
     unsigned long long want = (a.count + 64ull * nc - 1) / (64ull * nc);
-    unsigned long long cap = (unsigned long long)m->n_cu * (wg_per_cu > 0 ? wg_per_cu : 14);
+    unsigned long long cap = (unsigned long long)m->n_cu * (wg_per_cu > 0 ? wg_per_cu : 8);
     unsigned long long grid = want < cap ? want : cap;
     while ((a.count + grid - 1) / grid > 0x7FFFFFFFull) grid *= 2;
     if (carry_n16) {

@@ -909,6 +909,19 @@ def test_rank_large_search_for_heavy_values(big_model):
     info = rk.check()
     assert info["error"] == 0 and info["heavy_values"] > 1024
     assert torch.equal(rk.keys_sorted.view(torch.int64), torch.sort(keys.view(torch.int64))[0])
+    # the runs of the heavy values are written 16 bytes a lane: an output array that is only 8-byte aligned, both sizes
+    for n, mode in (((1 << 22) + 4097, 1), (1_000_003, 0)):
+        keys = m._dev.sample(n, 11)["ml2p"]
+        buf = torch.full((n + 3,), -1.0, dtype=torch.float64, device=dev)
+        nv.lib.mc_rank_debug_search(mode)
+        try:
+            rk = DeviceRank(keys, index="sorted", keys_sorted=buf[1:n + 1])
+            info = rk.check()
+        finally:
+            nv.lib.mc_rank_debug_search(0)
+        assert info["error"] == 0 and info["heavy_values"] > 100
+        assert torch.equal(buf[1:n + 1].view(torch.int64), torch.sort(keys.view(torch.int64))[0])
+        assert buf[0].item() == -1.0 and bool((buf[n + 1:] == -1.0).all())
 
 
 def test_sort_and_order_fuzz():

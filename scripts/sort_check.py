@@ -18,7 +18,7 @@ from montecarlo_amd.engine import DeviceRank
 
 def check(name, keys, reps=0):
     keys = keys.contiguous().cuda()
-    rk = DeviceRank(keys)
+    rk = DeviceRank(keys, index="sorted")
     info = rk.check()
     srt, _ = torch.sort(keys)
     ok = torch.equal(rk.keys_sorted.view(torch.int64), srt.view(torch.int64))

@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the model side (table compiler, k_sample, k_score) on random small corpora: random alphabets
+(2 .. 40 characters, some beyond ASCII), 10 .. 5000 lines with repeats, line lengths 1 .. 14; the backoff model at a
+random count threshold or the n-gram model at a random order, trained by the package's native trainer and -- apart --
+by the oracle's restatement of the reference's trainer (oracle/mc_oracle.py), sampled by the GPU and by the C oracle
+(oracle/mc_oracle.c) from the same Philox stream: -log2 p bit for bit, draw counts, lengths, strings; then the corpus'
+lines and mutated ones scored by both.  Usage: model_fuzz.py [cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("TQDM_DISABLE", "1")
+from montecarlo_amd import _native as nv  # noqa: E402
+from montecarlo_amd import synth  # noqa: E402
+from montecarlo_amd.backwords_simulator import BackWordsMonteCarlo  # noqa: E402
+from montecarlo_amd.nwords_simulator import NWordsMonteCarlo  # noqa: E402
+from oracle import c_oracle  # noqa: E402
+from oracle import mc_oracle as orc  # noqa: E402
+
+POOL = list("abcdefghijklmnopqrstuvwxyzABCDEFGHIJ0123456789!@#$%^&*._-+= ") + ["é", "ß", "ж", "中", "🙂"]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def corpus(rng):
+    k = int(rng.integers(2, 41))
+    alpha = [POOL[i] for i in rng.choice(len(POOL), size=k, replace=False)]
+    w = 1.0 / np.arange(1, k + 1) ** float(rng.uniform(0.3, 1.6))
+    w /= w.sum()
+    vocab = int(10 ** rng.uniform(0.7, 3.3))
+    words = []
+    for _ in range(vocab):
+        ln = 1 + min(13, int(rng.geometric(float(rng.uniform(0.12, 0.5)))))
+        words.append("".join(alpha[i] for i in rng.choice(k, size=ln, p=w)))
+    words += ["".join(alpha[i] for i in rng.choice(k, size=int(rng.integers(4, 9)), p=w)) for _ in range(3)]  # (some of >= min_len)
+    n = int(10 ** rng.uniform(1.0, 3.7))
+    zw = 1.0 / np.arange(1, len(words) + 1) ** float(rng.uniform(0.5, 1.3))
+    zw /= zw.sum()
+    return [words[i] for i in rng.choice(len(words), size=n, p=zw)], alpha
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for c in range(cases):
+        lines, alpha = corpus(rng)
+        if int(rng.integers(0, 2)):
+            thr = int(rng.choice([1, 2, 3, 5, 10, 30]))
+            what = f"backwords thr={thr}"
+            try:
+                probs, _ = orc.train_backwords(lines, "", "\x00", "\x03", 0, 1, thr, 256)
+            except ValueError:  # (no line length reaches the threshold: the reference's trainer raises there, max() of nothing)
+                try:
+                    BackWordsMonteCarlo(synth.as_file(lines), splitter="", threshold=thr)
+                    print(f"case {c:3d} {what}: the oracle's trainer refused the corpus, the package's did not: BAD", flush=True)
+                    bad += 1
+                except Exception as e:  # noqa: BLE001
+                    print(f"case {c:3d} {what}: refused by both trainers ({type(e).__name__})", flush=True)
+                continue
+            m = BackWordsMonteCarlo(synth.as_file(lines), splitter="", threshold=thr)
+            cm = c_oracle.COracleModel(orc.expand_table(probs), c_oracle.KIND_BACKOFF, start_units=["\x00"])
+        else:
+            n = int(rng.integers(2, 7))
+            what = f"nwords n={n}"
+            m = NWordsMonteCarlo(synth.as_file(lines), n=n, splitter="")
+            probs, _ = orc.train_nwords(lines, n, "", "\x03")
+            cm = c_oracle.COracleModel(orc.expand_table(probs), c_oracle.KIND_NGRAM, order=n - 1, start_units=["\x00"] * (n - 1))
+        count, sd, first = int(rng.integers(1, 30000)), int(rng.integers(0, 2 ** 62)), int(rng.integers(0, 2 ** 40))
+        res = m._dev.sample(count, sd, first_id=first, max_draws=2000, want_len=True, want_draws=True, sym_stride=20)
+        try:
+            cnt = m._dev.check()
+        except nv.NativeError as e:  # (a model whose walks do not end -- no line of min_len characters, say: NaN on both sides)
+            assert e.code == nv.ERR_DIVERGED, e
+            cnt = None
+        want = cm.sample(count, sd, first_id=first, max_draws=2000, stride=20)
+        got_x = res["ml2p"].cpu().numpy()
+        lost = np.isnan(want["ml2p"])
+        ok = (np.array_equal(np.isnan(got_x), lost) and np.array_equal(bits(got_x[~lost]), bits(want["ml2p"][~lost]))
+              and np.array_equal(res["draws"].cpu().numpy().astype(np.uint32), want["draws"])
+              and (cnt is None) == bool(lost.any()) and (cnt is None or cnt["draws"] == int(want["draws"].sum())))
+        keep = np.flatnonzero(~lost)
+        ok = ok and np.array_equal(res["len"].cpu().numpy().astype(np.uint32)[keep], want["len"][keep])
+        got_s = m._flat.decode(res["syms"].cpu().numpy()[keep], np.minimum(res["len"].cpu().numpy()[keep], 20))
+        want_s = cm.strings({"syms": want["syms"][keep], "len": np.minimum(want["len"][keep], 20)})
+        ok = ok and got_s == want_s
+        if cnt is None:
+            cnt = {"failed": int(lost.sum()), "indirect_draws": -1}
+        test = list(dict.fromkeys(lines))[:4000]
+        mut = []
+        for s in test[:1500]:
+            j = int(rng.integers(0, len(s)))
+            mut.append(s[:j] + alpha[int(rng.integers(0, len(alpha)))] + s[j + (int(rng.integers(0, 2))):])
+        test = test + mut + ["", "\x7f", alpha[0] * 40]
+        got, _ = m.score_batch(test)
+        ok2 = np.array_equal(bits(np.array(got)), bits(cm.score(test)))
+        if not (ok and ok2):
+            bad += 1
+        print(f"case {c:3d} {what:18s} lines={len(lines):5d} alphabet={len(alpha):2d} samples={count:5d} "
+              f"failed={cnt['failed']} indirect={cnt['indirect_draws']} sample={'ok' if ok else 'BAD'} "
+              f"score={'ok' if ok2 else 'BAD'}", flush=True)
+    print("ALL OK" if not bad else f"{bad} FAILED")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

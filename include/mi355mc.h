@@ -391,7 +391,11 @@ int mc_score(mc_model *m, const uint32_t *syms, const uint64_t *off, uint64_t co
  * out_split (may be NULL) receives split_words u64 per password: bit j set = a symbol of the best
  * parse ends after character j+1 of pwd + end_chr (all zero when unparseable).  max_len = an upper
  * bound on the password lengths of the batch (the DFS stack lives in `workspace`); a longer
- * password yields NaN and is reported by mc_model_check as a failed item. */
+ * password yields NaN and is reported by mc_model_check as a failed item.
+ * Cost: the reference's -- EVERY segmentation is visited.  Where the model's symbols include every short string over
+ * a small alphabet, a password of L characters has about 1.9^L of them (3e8 at L = 30): the launch then runs for as
+ * long as that walk takes and cannot be interrupted.  iter_max is the bound the reference offers, and the one to
+ * use for such models (scripts/model_fuzz.py met the case: bigrams over tokens of 1 .. 4 characters from 2 letters). */
 size_t mc_score_words_workspace_bytes(const mc_model *m, uint64_t count, uint32_t max_len);
 int mc_score_words(mc_model *m, const uint32_t *cps, const uint64_t *off, uint64_t count, uint32_t max_len,
                    uint64_t iter_max, double *out_ml2p, uint64_t *out_split, uint32_t split_words,

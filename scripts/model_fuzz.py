@@ -4,7 +4,9 @@
 random count threshold or the n-gram model at a random order, trained by the package's native trainer and -- apart --
 by the oracle's restatement of the reference's trainer (oracle/mc_oracle.py), sampled by the GPU and by the C oracle
 (oracle/mc_oracle.c) from the same Philox stream: -log2 p bit for bit, draw counts, lengths, strings; then the corpus'
-lines and mutated ones scored by both.  Usage: model_fuzz.py [cases] [seed]"""
+lines and mutated ones scored by both.  A quarter of the cases are sub-word models (tab-separated tokens of 1 .. 4
+characters: calc_ml2p's DFS over segmentations, values and component lists against the Python oracle, with a random
+max_iter), a quarter the v2 model at n = 2 .. 6.  Usage: model_fuzz.py [cases] [seed]"""
 import os
 import sys
 
@@ -17,6 +19,7 @@ from montecarlo_amd import _native as nv  # noqa: E402
 from montecarlo_amd import synth  # noqa: E402
 from montecarlo_amd.backwords_simulator import BackWordsMonteCarlo  # noqa: E402
 from montecarlo_amd.nwords_simulator import NWordsMonteCarlo  # noqa: E402
+from montecarlo_amd.nwords_simulator_v2 import NWords2MonteCarlo  # noqa: E402
 from oracle import c_oracle  # noqa: E402
 from oracle import mc_oracle as orc  # noqa: E402
 
@@ -44,12 +47,120 @@ def corpus(rng):
     return [words[i] for i in rng.choice(len(words), size=n, p=zw)], alpha
 
 
+def subword_corpus(rng):
+    """lines of 1 .. 5 tab-separated tokens of 1 .. 4 characters: many passwords have several segmentations"""
+    k = int(rng.integers(2, 12))
+    alpha = [POOL[i] for i in rng.choice(len(POOL) - 6, size=k, replace=False)]  # (no space: the trainers strip nothing, but keep it plain)
+    vocab = int(10 ** rng.uniform(0.5, 2.3)) + 2
+    toks = list(dict.fromkeys("".join(alpha[i] for i in rng.integers(0, k, size=int(rng.integers(1, 5)))) for _ in range(vocab)))
+    zw = 1.0 / np.arange(1, len(toks) + 1) ** float(rng.uniform(0.4, 1.2))
+    zw /= zw.sum()
+    n = int(10 ** rng.uniform(1.0, 3.3))
+    return ["\t".join(toks[i] for i in rng.choice(len(toks), size=int(rng.integers(1, 6)), p=zw)) for _ in range(n)], alpha
+
+
+def subword_case(rng, c):
+    """-> (ok, text): sampling against the C oracle, calc_ml2p's DFS (value and components) against the Python oracle"""
+    lines, alpha = subword_corpus(rng)
+    if int(rng.integers(0, 2)):
+        thr = int(rng.choice([1, 2, 5, 10]))
+        what = f"sub-word backwords thr={thr}"
+        try:
+            probs, words = orc.train_backwords(lines, "\t", "\x00", "\x03", 0, 1, thr, 256)
+        except ValueError:
+            try:
+                BackWordsMonteCarlo(synth.as_file(lines), splitter="\t", threshold=thr)
+                return False, f"case {c:3d} {what}: the oracle's trainer refused the corpus, the package's did not: BAD"
+            except Exception as e:  # noqa: BLE001
+                return True, f"case {c:3d} {what}: refused by both trainers ({type(e).__name__})"
+        max_iter = int(rng.choice([10 ** 100, 1, 2, 5]))
+        m = BackWordsMonteCarlo(synth.as_file(lines), splitter="\t", threshold=thr, max_iter=max_iter)
+        o = orc.BackoffOracle(probs, words, max_iter=max_iter)
+        cm = c_oracle.COracleModel(orc.expand_table(probs), c_oracle.KIND_BACKOFF, start_units=["\x00"])
+        what += f" max_iter={min(max_iter, 99)}"
+    else:
+        n = int(rng.integers(2, 4))
+        what = f"sub-word nwords n={n}"
+        m = NWordsMonteCarlo(synth.as_file(lines), n=n, splitter="\t")
+        probs, words = orc.train_nwords(lines, n, "\t", "\x03")
+        o = orc.NGramOracle(probs, words, n)
+        cm = c_oracle.COracleModel(orc.expand_table(probs), c_oracle.KIND_NGRAM, order=n - 1, start_units=["\x00"] * (n - 1))
+    count, sd, first = int(rng.integers(1, 20000)), int(rng.integers(0, 2 ** 62)), int(rng.integers(0, 2 ** 40))
+    res = m._dev.sample(count, sd, first_id=first, max_draws=2000, want_len=True, want_draws=True, sym_stride=24)
+    try:
+        m._dev.check()
+        lost_any = False
+    except nv.NativeError as e:
+        assert e.code == nv.ERR_DIVERGED, e
+        lost_any = True
+    want = cm.sample(count, sd, first_id=first, max_draws=2000, stride=24)
+    got_x = res["ml2p"].cpu().numpy()
+    lost = np.isnan(want["ml2p"])
+    keep = np.flatnonzero(~lost)
+    ok = (np.array_equal(np.isnan(got_x), lost) and np.array_equal(bits(got_x[~lost]), bits(want["ml2p"][~lost]))
+          and np.array_equal(res["draws"].cpu().numpy().astype(np.uint32), want["draws"]) and lost_any == bool(lost.any())
+          and np.array_equal(res["len"].cpu().numpy().astype(np.uint32)[keep], want["len"][keep]))
+    got_s = m._flat.decode(res["syms"].cpu().numpy()[keep], np.minimum(res["len"].cpu().numpy()[keep], 24))
+    want_s = cm.strings({"syms": want["syms"][keep], "len": np.minimum(want["len"][keep], 24)}, drop="\x00")
+    ok = ok and got_s == want_s
+    # (the DFS visits every segmentation, as the reference's does: the number of them grows like 1.9^length on a small
+    # alphabet, and the Python oracle walks them one by one -- passwords of at most 14 characters here)
+    test = [t for t in dict.fromkeys("".join(line.split("\t")) for line in lines) if len(t) <= 14][:250]
+    mut = []
+    for t in test[:100]:
+        j = int(rng.integers(0, len(t)))
+        mut.append(t[:j] + alpha[int(rng.integers(0, len(alpha)))] + t[j + (int(rng.integers(0, 2))):])
+    test = test + mut + ["", alpha[0] * 12]
+    print(f"case {c:3d} {what}: {len(test)} passwords through the DFS ...", flush=True)
+    got, parts = m.score_batch(test)
+    ref = [o.calc_ml2p(t) for t in test]
+    ok2 = np.array_equal(bits(np.array(got)), bits([r[0] for r in ref])) and parts == [r[1] for r in ref]
+    return ok and ok2, (f"case {c:3d} {what:34s} lines={len(lines):5d} alphabet={len(alpha):2d} samples={count:5d} "
+                        f"lost={int(lost.sum())} sample={'ok' if ok else 'BAD'} score={'ok' if ok2 else 'BAD'}")
+
+
+def v2_case(rng, c):
+    """the v2 model (contexts of characters, transitions of words) on a small synthetic corpus of its own format"""
+    n = int(rng.integers(2, 7))
+    lines = synth.v2_corpus(int(10 ** rng.uniform(1.5, 3.5)), vocab=int(10 ** rng.uniform(0.7, 2.8)) + 3,
+                            seed=int(rng.integers(0, 2 ** 31)))
+    m = NWords2MonteCarlo(synth.as_file(lines), n)
+    probs, _words = orc.train_v2(lines, n)
+    cm = c_oracle.COracleModel(orc.expand_table(probs), c_oracle.KIND_V2, order=n - 1, start_units=[], flags=1)
+    count, sd, first = int(rng.integers(1, 20000)), int(rng.integers(0, 2 ** 62)), int(rng.integers(0, 2 ** 40))
+    res = m._dev.sample(count, sd, first_id=first, max_draws=2000, want_len=True, want_draws=True, sym_stride=24)
+    try:
+        m._dev.check()
+        lost_any = False
+    except nv.NativeError as e:
+        assert e.code == nv.ERR_DIVERGED, e
+        lost_any = True
+    want = cm.sample(count, sd, first_id=first, max_draws=2000, stride=24)
+    got_x = res["ml2p"].cpu().numpy()
+    lost = np.isnan(want["ml2p"])
+    keep = np.flatnonzero(~lost)
+    ok = (np.array_equal(np.isnan(got_x), lost) and np.array_equal(bits(got_x[~lost]), bits(want["ml2p"][~lost]))
+          and np.array_equal(res["draws"].cpu().numpy().astype(np.uint32), want["draws"]) and lost_any == bool(lost.any())
+          and np.array_equal(res["len"].cpu().numpy().astype(np.uint32)[keep], want["len"][keep]))
+    got_s = m._flat.decode(res["syms"].cpu().numpy()[keep], np.minimum(res["len"].cpu().numpy()[keep], 24))
+    want_s = cm.strings({"syms": want["syms"][keep], "len": np.minimum(want["len"][keep], 24)})
+    ok = ok and got_s == want_s
+    return ok, (f"case {c:3d} v2 n={n}                             lines={len(lines):5d} samples={count:5d} "
+                f"lost={int(lost.sum())} sample={'ok' if ok else 'BAD'}")
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
     bad = 0
     for c in range(cases):
+        mode = int(rng.integers(0, 4))
+        if mode >= 2:
+            ok, text = (subword_case if mode == 2 else v2_case)(rng, c)
+            bad += 0 if ok else 1
+            print(text, flush=True)
+            continue
         lines, alpha = corpus(rng)
         if int(rng.integers(0, 2)):
             thr = int(rng.choice([1, 2, 3, 5, 10, 30]))

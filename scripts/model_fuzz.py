@@ -211,11 +211,22 @@ def main():
         test = test + mut + ["", "\x7f", alpha[0] * 40]
         got, _ = m.score_batch(test)
         ok2 = np.array_equal(bits(np.array(got)), bits(cm.score(test)))
-        if not (ok and ok2):
+        # the threshold enumerators (mc_enumerate) against the reference's recursion as the oracle restates it: every
+        # string with -log2 p below a random threshold (fewer than 2^threshold of them), in the reference's order
+        thr_e = float(rng.uniform(3.0, 15.0))
+        if what.startswith("backwords"):
+            want_e = orc.enumerate_strings(probs, thr_e, "\x00", "\x03", 4)
+            e_ml2p, e_lens, e_syms = m._dev.enumerate(thr_e, 4, 256)
+        else:
+            want_e = orc.enumerate_strings(probs, thr_e, "\x00", "\x03", 4, order=n - 1)
+            e_ml2p, e_lens, e_syms = m._dev.enumerate(thr_e, 4, 30)
+        ok3 = (len(e_ml2p) == len(want_e) and m._flat.decode(e_syms, e_lens) == [w[0] for w in want_e]
+               and np.array_equal(bits(e_ml2p), bits([w[1] for w in want_e])))
+        if not (ok and ok2 and ok3):
             bad += 1
         print(f"case {c:3d} {what:18s} lines={len(lines):5d} alphabet={len(alpha):2d} samples={count:5d} "
               f"failed={cnt['failed']} indirect={cnt['indirect_draws']} sample={'ok' if ok else 'BAD'} "
-              f"score={'ok' if ok2 else 'BAD'}", flush=True)
+              f"score={'ok' if ok2 else 'BAD'} enumerated={len(want_e)} {'ok' if ok3 else 'BAD'}", flush=True)
     print("ALL OK" if not bad else f"{bad} FAILED")
     sys.exit(1 if bad else 0)
 

@@ -4,9 +4,10 @@
 random count threshold or the n-gram model at a random order, trained by the package's native trainer and -- apart --
 by the oracle's restatement of the reference's trainer (oracle/mc_oracle.py), sampled by the GPU and by the C oracle
 (oracle/mc_oracle.c) from the same Philox stream: -log2 p bit for bit, draw counts, lengths, strings; then the corpus'
-lines and mutated ones scored by both.  A quarter of the cases are sub-word models (tab-separated tokens of 1 .. 4
+lines and mutated ones scored by both.  A fifth of the cases are sub-word models (tab-separated tokens of 1 .. 4
 characters: calc_ml2p's DFS over segmentations, values and component lists against the Python oracle, with a random
-max_iter), a quarter the v2 model at n = 2 .. 6.  Usage: model_fuzz.py [cases] [seed]"""
+max_iter), a fifth the v2 model at n = 2 .. 6, a fifth BPE-PCFG model
+directories (k_sample_bpe / k_score_bpe against BpeOracle).  Usage: model_fuzz.py [cases] [seed]"""
 import os
 import sys
 
@@ -149,15 +150,96 @@ def v2_case(rng, c):
                 f"lost={int(lost.sum())} sample={'ok' if ok else 'BAD'}")
 
 
+def bpe_dir(path, rng):
+    """a small random BPE-PCFG model directory (the format bpeX/modelreader.py reads): terminal rows of 1 .. 500
+    entries for a random choice of classes and lengths, mixed-class rows in half the cases, 1 .. 40 structures"""
+    for sub in ("grammar", "lower", "upper", "mixed_2", "mixed_3", "mixed_4", "digits", "special"):
+        os.makedirs(os.path.join(path, sub), exist_ok=True)
+    alpha = {"lower": "abcdefghij", "upper": "ABCDEF", "digits": "0123456789", "special": "!@#._"}
+    tag = {"lower": "L", "upper": "U", "digits": "D", "special": "S", "mixed_2": "DM", "mixed_3": "TM", "mixed_4": "FM"}
+    if int(rng.integers(0, 2)):
+        both = alpha["lower"] + alpha["digits"]
+        alpha.update({"mixed_2": both, "mixed_3": both + alpha["upper"], "mixed_4": both + alpha["special"]})
+    have = []
+    for sub, chars in alpha.items():
+        chars = np.array(list(chars))
+        low = {"mixed_2": 2, "mixed_3": 3, "mixed_4": 4}.get(sub, 1)
+        for ln in range(low, low + int(rng.integers(1, 5))):
+            if int(rng.integers(0, 4)) == 0 and have:
+                continue
+            n = min(int(10 ** rng.uniform(0, 2.7)), len(chars) ** ln)
+            terms = set()
+            while len(terms) < n:
+                terms.update("".join(r) for r in rng.choice(chars, size=(n, ln)))
+            terms = sorted(terms)[:n]
+            rng.shuffle(terms)
+            w = 1.0 / np.arange(1, n + 1) ** float(rng.uniform(0.2, 1.5))
+            w /= w.sum()
+            with open(os.path.join(path, sub, f"{ln}.txt"), "w") as f:
+                for t, p in zip(terms, w):
+                    f.write(f"{t}\t{float(p)!r}\n")
+            have.append((tag[sub], ln))
+    structs = set()
+    want = min(int(rng.integers(1, 41)), len(have))
+    while len(structs) < want:
+        k = int(rng.integers(1, 5))
+        segs = [have[int(i)] for i in rng.integers(0, len(have), size=k)]
+        if all(a[0] != b[0] for a, b in zip(segs, segs[1:])):
+            structs.add("".join(f"{t}{n}" for t, n in segs))
+    structs = sorted(structs)
+    w = 1.0 / np.arange(1, len(structs) + 1) ** float(rng.uniform(0.3, 1.4))
+    w /= w.sum()
+    with open(os.path.join(path, "grammar", "structures.txt"), "w") as f:
+        for s_, p in zip(structs, w):
+            f.write(f"{s_}\t{float(p)!r}\n")
+    return len(structs)
+
+
+def bpe_case(rng, c):
+    """k_sample_bpe / k_score_bpe against BpeOracle (bpe_simulator.py:105-150 restated) on a random model directory"""
+    import tempfile
+    from montecarlo_amd.bpe_simulator import BpePcfgSim
+    from oracle.philox import SampleStream
+    with tempfile.TemporaryDirectory() as tmp:
+        ns = bpe_dir(tmp, rng)
+        m = BpePcfgSim(tmp)
+        o = orc.BpeOracle(*orc.read_bpe(tmp))
+    count, sd, first = int(rng.integers(1, 3000)), int(rng.integers(0, 2 ** 62)), int(rng.integers(0, 2 ** 40))
+    res = m._dev.sample(count, sd, first_id=first, want_draws=True, want_len=True, sym_stride=m._flat.max_segments)
+    cnt = m._dev.check()
+    got_s = m._flat.decode_entries(res["syms"].cpu().numpy(), res["len"].cpu().numpy())
+    want_x, want_s, want_d = [], [], []
+    for i in range(count):
+        st = SampleStream(sd, first + i)
+        x, t = o.sample1(st)
+        want_x.append(x)
+        want_s.append(t)
+        want_d.append(st.draws)
+    ok = (np.array_equal(bits(res["ml2p"].cpu().numpy()), bits(want_x)) and got_s == want_s
+          and np.array_equal(res["draws"].cpu().numpy().astype(np.int64), np.array(want_d)) and cnt["failed"] == 0)
+    uniq = list(dict.fromkeys(want_s))[:1500]
+    alphabet = "abcjABF019!@._~ é"
+    mut = []
+    for t in uniq[:700]:
+        if t:
+            j = int(rng.integers(0, len(t)))
+            mut.append(t[:j] + alphabet[int(rng.integers(0, len(alphabet)))] + t[j + (int(rng.integers(0, 2))):])
+    pw = uniq + mut + ["", "~~~~", "a" * 40, "aB1!aB1!"]
+    got, _parts = m.score_batch(pw)
+    ok2 = np.array_equal(bits(got), bits([o.calc_ml2p(t) for t in pw]))
+    return ok and ok2, (f"case {c:3d} bpe-pcfg structures={ns:2d}                 samples={count:5d} "
+                        f"sample={'ok' if ok else 'BAD'} score={'ok' if ok2 else 'BAD'}")
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
     bad = 0
     for c in range(cases):
-        mode = int(rng.integers(0, 4))
+        mode = int(rng.integers(0, 5))
         if mode >= 2:
-            ok, text = (subword_case if mode == 2 else v2_case)(rng, c)
+            ok, text = (subword_case, v2_case, bpe_case)[mode - 2](rng, c)
             bad += 0 if ok else 1
             print(text, flush=True)
             continue

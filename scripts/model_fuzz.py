@@ -293,6 +293,26 @@ def main():
         test = test + mut + ["", "\x7f", alpha[0] * 40]
         got, _ = m.score_batch(test)
         ok2 = np.array_equal(bits(np.array(got)), bits(cm.score(test)))
+        # parse_file (MonteCarloParent.py:48-69: lines stripped of "\r\n", deduplicated in first-seen order, scored, put
+        # in stable order of ml2p) on a text of repeated lines with every kind of line end, against the same loop in
+        # Python over the C oracle's scores; the native ingest when the text holds no "\r", the line loop when it does
+        import io
+        ends = ["\n"] if int(rng.integers(0, 2)) else ["\n", "\r\n", "\r\r\n"]
+        picks = rng.integers(0, len(test), size=int(rng.integers(0, 4000)))
+        text_f = "".join(test[i] + ends[int(rng.integers(0, len(ends)))] for i in picks)
+        if len(picks) and int(rng.integers(0, 2)):
+            text_f = text_f.rstrip("\r\n")                                   # (no line end after the last line)
+        seen = {}
+        for line in io.StringIO(text_f):
+            line = line.strip("\r\n")
+            seen[line] = seen.get(line, 0) + 1
+        uniq_l = list(seen)
+        sc_l = cm.score(uniq_l) if uniq_l else np.zeros(0)
+        want_p = sorted(((p, seen[p], float(x)) for p, x in zip(uniq_l, sc_l)), key=lambda r: r[2])
+        got_p = m.parse_file(io.StringIO(text_f))
+        ok4 = len(got_p) == len(want_p) and all(
+            (g[0], g[1]) == (w[0], w[1]) and bits([g[2]])[0] == bits([w[2]])[0] for g, w in zip(got_p, want_p))
+        ok = ok and ok4
         # the threshold enumerators (mc_enumerate) against the reference's recursion as the oracle restates it: every
         # string with -log2 p below a random threshold (fewer than 2^threshold of them), in the reference's order
         thr_e = float(rng.uniform(3.0, 15.0))
@@ -308,7 +328,7 @@ def main():
             bad += 1
         print(f"case {c:3d} {what:18s} lines={len(lines):5d} alphabet={len(alpha):2d} samples={count:5d} "
               f"failed={cnt['failed']} indirect={cnt['indirect_draws']} sample={'ok' if ok else 'BAD'} "
-              f"score={'ok' if ok2 else 'BAD'} enumerated={len(want_e)} {'ok' if ok3 else 'BAD'}", flush=True)
+              f"score={'ok' if ok2 else 'BAD'} parse_file={len(want_p)} {'ok' if ok4 else 'BAD'} enumerated={len(want_e)} {'ok' if ok3 else 'BAD'}", flush=True)
     print("ALL OK" if not bad else f"{bad} FAILED")
     sys.exit(1 if bad else 0)
 

@@ -13,6 +13,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.fixture(autouse=True)
+def fresh_rank_choices():
+    """DeviceRank remembers the size from which the run index was refused (engine.runs_index_wanted): what the
+    fuzzers' key sets taught it must not reach the tests that follow."""
+    from montecarlo_amd import engine
+    engine.forget_rank_choices()
+    yield
+    engine.forget_rank_choices()
+
+
 def run_script(name, *args):
     path = os.path.join(ROOT, "scripts", name)
     spec = importlib.util.spec_from_file_location(name[:-3] + "_under_test", path)

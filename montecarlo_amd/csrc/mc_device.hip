@@ -1819,8 +1819,10 @@ extern "C" int mc_score(mc_model *m, const uint32_t *syms, const uint64_t *off, 
                      "mc_score_words; BPE-PCFG: mc_score_bpe)");
         return MC_ERR_ARG;
     }
-    static const int env_swg = getenv("MC_SCORE_WG_PER_CU") ? atoi(getenv("MC_SCORE_WG_PER_CU")) : 8;
-    unsigned long long want = (count + 255) / 256, cap = (unsigned long long)m->n_cu * (env_swg > 0 ? env_swg : 8);
+    // (16 workgroups a CU: 1e6 passwords are one a lane -- beside the sampler, where the bench scores its test set, the
+    // step takes 0.596 ms against 0.600 with 8, 0.603 with 4, 0.612 with 2; 32 as 16)
+    static const int env_swg = getenv("MC_SCORE_WG_PER_CU") ? atoi(getenv("MC_SCORE_WG_PER_CU")) : 16;
+    unsigned long long want = (count + 255) / 256, cap = (unsigned long long)m->n_cu * (env_swg > 0 ? env_swg : 16);
     dim3 g((unsigned)(want < cap ? want : cap)), b(256);
     // passwords a lane walks at a time: one on the dense table (scripts/exp_score_grid.py, 1e6 passwords: the bench's
     // test set 0.040 ms against 0.051 with two, distinct strings 0.052 against 0.059), two on the hash path

@@ -48,7 +48,10 @@ __device__ __forceinline__ u64 order_bits(u64 b) { return mc_sort_order_word(b);
 // words[p] = (index of the first sorted key equal to x[p]'s) << 32 | p.  The search runs in two stages: every
 // OW_STRIDE-th sorted key is staged in LDS and searched there, the rest of the search is confined to one stride of
 // the sorted array (20 dependent reads from memory per password were most of this kernel's time).
-constexpr int OW_THREADS = 256, OW_LDS = 4096;
+// (1024 staged keys and 1024 lanes a workgroup: two passwords a lane, one after the other, instead of eight, and a
+// quarter of the scattered reads that stage the keys -- the step 0.599 ms against 0.610 with 4096 / 256; 512 / 512
+// 0.5995, 1024 / 512 0.602, 256 / 1024 0.602, 4096 / 512 0.605)
+constexpr int OW_THREADS = 1024, OW_LDS = 1024;
 constexpr int LS_THREADS = 512, LS_ROUNDS = 4, LS_TILE = LS_THREADS * LS_ROUNDS, LS_CHUNKS = LS_TILE / 64;
 constexpr u64 LS_MAX_T = 1ull << 24;
 static_assert(LS_TILE % OW_THREADS == 0, "k_order_words walks the LSD passes' tiles");

@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(LS_THREADS) k_lsd_scatter(const u32 *__restric
     const u32 tile = blockIdx.x;
     for (int i = tid; i < LS_CHUNKS * 256 / 2; i += LS_THREADS) ((u32 *)cc)[i] = 0;
     {   // first place of every digit in the output + this tile's places after the earlier tiles'
-        const u32 v = tid < 256 ? totals[tid] : 0u;
+        const u32 v = tid <= (int)mask ? totals[tid] : 0u;  // (mask <= 255: the digits in use; k_lsd_scan wrote no other total)
         u32 inc = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -568,7 +568,8 @@ extern "C" int mc_order_keys_begin(const double *x, uint64_t t, double *x_sorted
         int passes, width;
         lsd_passes(t, passes, width);
         u32 *table = (u32 *)((char *)o.failed + 256);
-        hipLaunchKernelGGL(k_order_words<false>, dim3(o.gw), dim3(OW_THREADS), 0, s, (const u64 *)x_sorted, (const u64 *)x,
+        // (a workgroup walks whole tiles: none beyond their number -- each stages its keys first, for nothing if it has no tile)
+        hipLaunchKernelGGL(k_order_words<false>, dim3(o.gw < tiles ? o.gw : tiles), dim3(OW_THREADS), 0, s, (const u64 *)x_sorted, (const u64 *)x,
                            (u64)t, o.stride, o.words, (const u32 *)err1, o.failed, (u64 *)x_values, table, tiles,
                            (1u << width) - 1u);
     } else {
@@ -607,7 +608,7 @@ extern "C" int mc_order_keys_end(const double *x, uint64_t t, double *x_sorted, 
             const u32 shift = (u32)(ps * width), mask = (1u << width) - 1u;
             if (ps)  // (the first pass's histograms are mc_order_keys_begin's: its search kernel counted them)
                 hipLaunchKernelGGL(k_lsd_hist, dim3(tiles), dim3(LS_THREADS), 0, s, kin, (u64)t, shift, mask, tiles, table);
-            hipLaunchKernelGGL(k_lsd_scan, dim3(256), dim3(256), 0, s, table, tiles, totals);
+            hipLaunchKernelGGL(k_lsd_scan, dim3(mask + 1u), dim3(256), 0, s, table, tiles, totals);  // (a workgroup a digit in use)
             hipLaunchKernelGGL(k_lsd_scatter, dim3(tiles), dim3(LS_THREADS), 0, s, kin, pin, (u64)t, shift, mask, width,
                                tiles, (const u32 *)table, (const u32 *)totals, last ? (u32 *)nullptr : kout, pout,
                                last ? (const u64 *)x : (const u64 *)nullptr, (u64 *)x_sorted, (const u32 *)o.failed);

@@ -1924,7 +1924,9 @@ int mc_sort_keys(const uint64_t *in, uint64_t n, uint64_t *out, void *workspace,
         hipLaunchKernelGGL(k_fill<true>, dim3(FILL_GRID_BIG), dim3(256), 0, s, w);
     } else {
         hipLaunchKernelGGL(k_finish<false>, dim3(g_ft), dim3(WG), 0, s, w);
-        if (!few_repeats) hipLaunchKernelGGL(k_fill<false>, dim3(1024), dim3(256), 0, s, w);  // (no heavy values: no runs)
+        // (no heavy values: no runs.  A workgroup writes 4096 copies at a time and there are at most n: no workgroups beyond)
+        const u32 g_fill = (u32)(n / 4096 + 1 < 1024 ? n / 4096 + 1 : 1024);
+        if (!few_repeats) hipLaunchKernelGGL(k_fill<false>, dim3(g_fill), dim3(256), 0, s, w);
     }
     HIP_TRY(hipGetLastError());
     return MC_OK;

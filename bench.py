@@ -188,6 +188,10 @@ def main():
                     help="the main stream waits for the whole stable order of the test set (mc_order_keys) before its "
                          "queries; by default it waits for the sorted scores only (mc_order_keys_begin) and the "
                          "passwords' order is finished beside the queries (mc_order_keys_end)")
+    ap.add_argument("--order-wait", action="store_true",
+                    help="a step's sampling waits until the previous step's order of the passwords is whole (the second "
+                         "stream is in order anyway and the sets are double-buffered: the wait is a choice, not a need; "
+                         "0.595 ms a step with it, 0.591 without)")
     ap.add_argument("--no-fused-query", action="store_true",
                     help="one GPU, run index: answer the queries in a launch of their own (mc_rank_runs_query + "
                          "mc_guess_numbers, three launches) instead of inside the guess numbers' first kernel")
@@ -300,9 +304,11 @@ def main():
             marks = [torch.cuda.Event() if i in needed else _NoMark for i in range(13)]
         slot = it & 1
         first = first_id(it, world, rank, N)                # disjoint Philox sample ids per rank and step
-        if side is not None and not args.whole_order and order_done[slot ^ 1] is not None:
-            # a step's results are whole before the next one samples (and the order's last launches do not sit beside
-            # the sampler, which they slow: 0.622 ms a step without this wait, 0.619 with it)
+        if side is not None and not args.whole_order and order_done[slot ^ 1] is not None and args.order_wait:
+            # --order-wait: a step's results are whole before the next one samples, and the order's last launches do not
+            # sit beside the sampler (0.619 ms a step against 0.622 when the second stream was the longer one by far; since
+            # its launches were trimmed, r03_o, the wait costs: 0.595 against 0.591).  Without it nothing is unordered:
+            # the second stream runs its launches in order and every set of buffers is written two steps apart.
             main_stream.wait_event(order_done[slot ^ 1])
             order_done[slot ^ 1] = None
         marks[0].record()

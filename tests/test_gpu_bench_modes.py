@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("extra", [[], ["--serial"], ["--serial", "--d2h", "inline"], ["--d2h", "overlap"],
                                    ["--d2h-all"], ["--serial", "--sample-wg-per-cu", "7", "--steps", "1", "--warmup", "0"],
                                    ["--rank-index", "sorted"], ["--rank-index", "sorted", "--serial", "--d2h", "inline"],
-                                   ["--whole-order"], ["--whole-order", "--d2h-all"], ["--no-fused-query"]],
+                                   ["--whole-order"], ["--whole-order", "--d2h-all"], ["--no-fused-query"], ["--order-wait"],
+                                   ["--order-wait", "--d2h-all"]],
                          ids=lambda e: " ".join(e) or "default")
 def test_bench_step_arrangements(extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--samples", "300000", "--tests", "30001", "--train-lines",

@@ -313,6 +313,27 @@ def main():
         ok4 = len(got_p) == len(want_p) and all(
             (g[0], g[1]) == (w[0], w[1]) and bits([g[2]])[0] == bits([w[2]])[0] for g, w in zip(got_p, want_p))
         ok = ok and ok4
+        # MonteCarlo.sample(size, sampled_pwds) (MonteCarloParent.py:26-46): the dict of distinct sampled strings built
+        # from the GPU's dedup (one row per distinct string reaches the host; strings longer than the kept stride are
+        # replayed) against the one built from every sample of the C oracle, content and first-sampled order
+        ok5, n_distinct = True, -1
+        if not lost.any():
+            nd, sd2 = min(count, 5000), int(rng.integers(0, 2 ** 62))
+            want_d = cm.sample(nd, sd2, max_draws=1 << 16, stride=64)
+            if int(want_d["len"].max()) <= 64 and not np.isnan(want_d["ml2p"]).any():
+                ref_d = {}
+                for x, pwd in zip(want_d["ml2p"].tolist(), cm.strings({"syms": want_d["syms"], "len": want_d["len"]})):
+                    ref_d.setdefault(pwd, [x, 0])[1] += 1
+                stride_d = int(rng.choice([32, 7, 3]))
+                m._sample_stride = lambda stride_d=stride_d: stride_d
+                m.seed(sd2)
+                got_d = {"stale": [0.0, 1]}
+                keys_d = m.sample(nd, got_d)
+                del m._sample_stride
+                ok5 = (list(got_d.items()) == list(ref_d.items())
+                       and np.array_equal(bits(keys_d.tolist()), bits(want_d["ml2p"])))
+                n_distinct = len(ref_d)
+        ok = ok and ok5
         # the threshold enumerators (mc_enumerate) against the reference's recursion as the oracle restates it: every
         # string with -log2 p below a random threshold (fewer than 2^threshold of them), in the reference's order
         thr_e = float(rng.uniform(3.0, 15.0))
@@ -328,7 +349,7 @@ def main():
             bad += 1
         print(f"case {c:3d} {what:18s} lines={len(lines):5d} alphabet={len(alpha):2d} samples={count:5d} "
               f"failed={cnt['failed']} indirect={cnt['indirect_draws']} sample={'ok' if ok else 'BAD'} "
-              f"score={'ok' if ok2 else 'BAD'} parse_file={len(want_p)} {'ok' if ok4 else 'BAD'} enumerated={len(want_e)} {'ok' if ok3 else 'BAD'}", flush=True)
+              f"score={'ok' if ok2 else 'BAD'} parse_file={len(want_p)} {'ok' if ok4 else 'BAD'} dedup={n_distinct} {'ok' if ok5 else 'BAD'} enumerated={len(want_e)} {'ok' if ok3 else 'BAD'}", flush=True)
     print("ALL OK" if not bad else f"{bad} FAILED")
     sys.exit(1 if bad else 0)
 

@@ -1059,7 +1059,10 @@ __global__ void __launch_bounds__(256) k_sample_bpe(DevModel m, SampleArgs a) {
         double r;
         next_uniform(m53, r);
         DrawRec q = draw_one<INJECT>(m, m.start_draw, m.start_gbits, m53, r, c_probes, c_indirect);
-        double acc = rec_f64(q);
+        // prob = .0; prob += p (bpe_simulator.py:107-109): the sum STARTS at +0.0 -- a structure of probability 1 is stored
+        // as -log2(1) = -0.0, and -0.0 alone (or plus the -0.0 of terminals of probability 1) would stay -0.0, which is
+        // not the reference's bits and sorts above every other key (scripts/model_fuzz.py found it: one structure, one terminal)
+        double acc = 0.0 + rec_f64(q);
         const uint32_t st = q.w2;  // entry of row 0 = structure index
         const uint32_t s0 = m.seg_off[st], s1 = m.seg_off[st + 1];
         bool ok = true;

@@ -43,6 +43,8 @@ def corpus(rng):
         words.append("".join(alpha[i] for i in rng.choice(k, size=ln, p=w)))
     words += ["".join(alpha[i] for i in rng.choice(k, size=int(rng.integers(4, 9)), p=w)) for _ in range(3)]  # (some of >= min_len)
     n = int(10 ** rng.uniform(1.0, 3.7))
+    if rng.random() < 0.12:                                  # a corpus of one to three distinct lines: rows of a single
+        words = words[-int(rng.integers(1, 4)):]             # entry, probabilities of exactly 1 (-log2 p = -0.0)
     zw = 1.0 / np.arange(1, len(words) + 1) ** float(rng.uniform(0.5, 1.3))
     zw /= zw.sum()
     return [words[i] for i in rng.choice(len(words), size=n, p=zw)], alpha
@@ -180,7 +182,7 @@ def bpe_dir(path, rng):
                     f.write(f"{t}\t{float(p)!r}\n")
             have.append((tag[sub], ln))
     structs = set()
-    want = min(int(rng.integers(1, 41)), len(have))
+    want = min(int(rng.integers(1, 41)) if rng.random() > 0.15 else 1, len(have))
     while len(structs) < want:
         k = int(rng.integers(1, 5))
         segs = [have[int(i)] for i in rng.integers(0, len(have), size=k)]
@@ -217,6 +219,15 @@ def bpe_case(rng, c):
         want_d.append(st.draws)
     ok = (np.array_equal(bits(res["ml2p"].cpu().numpy()), bits(want_x)) and got_s == want_s
           and np.array_equal(res["draws"].cpu().numpy().astype(np.int64), np.array(want_d)) and cnt["failed"] == 0)
+    if not ok:                                               # (what differs, for whoever reads the log)
+        gx, gd = res["ml2p"].cpu().numpy(), res["draws"].cpu().numpy()
+        shown = 0
+        for i in range(count):
+            if (bits([gx[i]])[0] != bits([want_x[i]])[0] or got_s[i] != want_s[i] or int(gd[i]) != want_d[i]) and shown < 4:
+                print(f"   sample {i} (id {first + i}): oracle ({want_x[i]!r}, {want_s[i]!r}, {want_d[i]} draws), "
+                      f"here ({gx[i]!r}, {got_s[i]!r}, {int(gd[i])} draws)", flush=True)
+                shown += 1
+        print(f"   counters {cnt}; seed {sd}", flush=True)
     uniq = list(dict.fromkeys(want_s))[:1500]
     alphabet = "abcjABF019!@._~ é"
     mut = []

@@ -11,6 +11,7 @@ nwords_simulator.py:36-60, backwords_simulator.py:28-49."""
 import tempfile
 
 import numpy as np
+import torch
 import pytest
 
 from conftest import golden, hx  # noqa: F401
@@ -99,6 +100,37 @@ def test_bpe_config4_shape():
     assert np.array_equal(bits(fast), bits(walk))
     assert np.array_equal(bits(fast[:len(pw)]), bits(want))
     assert np.array_equal(bits(fast[len(pw):]), bits([o.calc_ml2p(p) for p in longer]))
+
+
+def test_bpe_certain_structure_samples_plus_zero():
+    """A structure of probability 1 over terminals of probability 1: every stored -log2 p is -0.0, and the reference's
+    sum starts at +0.0 (`prob = .0; prob += p`, bpe_simulator.py:107-109), so a sample's key is +0.0 -- not -0.0, whose
+    bits are the largest of all in the key sort.  (scripts/model_fuzz.py found k_sample_bpe starting at the first value.)"""
+    import os
+    from montecarlo_amd.bpe_simulator import BpePcfgSim
+    from montecarlo_amd.engine import DeviceRank
+    with tempfile.TemporaryDirectory() as tmp:
+        for sub in ("grammar", "lower", "upper", "mixed_2", "mixed_3", "mixed_4", "digits", "special"):
+            os.makedirs(os.path.join(tmp, sub))
+        with open(os.path.join(tmp, "grammar", "structures.txt"), "w") as f:
+            f.write("L2D1\t1.0\n")
+        with open(os.path.join(tmp, "lower", "2.txt"), "w") as f:
+            f.write("ab\t1.0\n")
+        with open(os.path.join(tmp, "digits", "1.txt"), "w") as f:
+            f.write("7\t1.0\n")
+        m = BpePcfgSim(tmp)
+        o = orc.BpeOracle(*orc.read_bpe(tmp))
+    res = m._dev.sample(5000, 3, first_id=11, want_len=True, sym_stride=m._flat.max_segments)
+    assert m._dev.check()["failed"] == 0
+    keys = res["ml2p"]
+    assert bool((keys.view(torch.int64) == 0).all())                       # +0.0, bit for bit
+    x, s = o.sample1(SampleStream(3, 11))
+    assert bits([x])[0] == 0 and s == "ab7"
+    assert set(m._flat.decode_entries(res["syms"].cpu().numpy(), res["len"].cpu().numpy())) == {"ab7"}
+    rk = DeviceRank(torch.cat([keys, torch.full((5,), 2.5, dtype=torch.float64, device=keys.device)]))
+    assert rk.check()["error"] == 0 and float(rk.keys_sorted[0]) == 0.0 and float(rk.keys_sorted[-1]) == 2.5
+    got, _ = m.score_batch(["ab7", "ab8"])
+    assert bits(got)[0] == bits([o.calc_ml2p("ab7")])[0] and got[1] == orc.UNPARSEABLE
 
 
 def test_v2_n6_config3_model_matches_c_oracle():

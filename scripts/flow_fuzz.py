@@ -22,9 +22,11 @@ from oracle import mc_oracle as orc  # noqa: E402
 REL = 1e-9
 
 
-def samples(rng):
+def samples(rng, distinct_and_large=False):
     n = int(10 ** rng.uniform(0, 5.5))
-    kind = int(rng.integers(0, 4))
+    kind = int(rng.integers(0, 5))
+    if distinct_and_large:                           # (the case that settles on the expanded arrays, once a run for certain)
+        n, kind = 300000, 1
     if kind == 0:                                    # score-like: heavy values over a tail of repeated ones
         distinct = int(10 ** rng.uniform(0, 4)) + 1
         tail = np.round(rng.random(n) * distinct) / 64 + 3
@@ -35,6 +37,8 @@ def samples(rng):
         x = rng.random(n) * 60 + 1
     elif kind == 2:                                  # few values
         x = rng.integers(0, int(rng.integers(1, 40)), size=n) / 4 + 2.0
+    elif kind == 4:                                  # certain strings: -log2 p = +0.0 for many samples, tiny values beside
+        x = np.where(rng.random(n) < 0.5, 0.0, rng.integers(0, 6, size=n) * 2.0 ** -int(rng.integers(1, 60)))
     else:                                            # clusters at several scales
         x = 10 + rng.integers(0, 30, size=n) + rng.integers(0, 5, size=n) * 2.0 ** -20 + (rng.random(n) < 0.1) * rng.random(n)
     return [float(v) for v in x], kind
@@ -54,6 +58,9 @@ def scored(rng, keys):
         xs[rng.random(t) < 0.1] = k.min() - 1
         xs[rng.random(t) < 0.1] = k.max() + 1
     xs = np.maximum(xs, 0.0)
+    if t and rng.random() < 0.3:                     # both zeros among the scores (k_score_bpe's -0.0 is the reference's)
+        xs[rng.random(t) < 0.2] = -0.0
+        xs[rng.random(t) < 0.1] = 0.0
     out = [(f"pw{i}", int(rng.integers(1, 50)), float(x)) for i, x in enumerate(xs)]
     resort = bool(rng.integers(0, 2))
     if not resort:
@@ -66,7 +73,7 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     bad = 0
     for c in range(cases):
-        keys, kind = samples(rng)
+        keys, kind = samples(rng, distinct_and_large=(c == 0))
         sc, resort = scored(rng, keys)
         add1 = bool(rng.integers(0, 2))
         a, b = list(keys), list(keys)

@@ -48,7 +48,7 @@ def test_model_side_fuzz(capsys):
 
 
 def test_estimator_flow_fuzz(capsys):
-    run_script("flow_fuzz.py", 60, 1)            # (seed 1: both kinds of index among its first 60 cases)
+    run_script("flow_fuzz.py", 60, 1)            # (its first case is one the run index refuses: both kinds of index)
     out = capsys.readouterr().out
     assert "ALL OK" in out and "index=runs" in out and "index=sorted" in out and "write2=ok" in out
 

@@ -324,6 +324,40 @@ def main():
         ok4 = len(got_p) == len(want_p) and all(
             (g[0], g[1]) == (w[0], w[1]) and bits([g[2]])[0] == bits([w[2]])[0] for g, w in zip(got_p, want_p))
         ok = ok and ok4
+        # injected uniforms AT the rows' thresholds: r = cum[i] / total and its neighbours one ulp below and above (where
+        # bisect_right(cum, total * r) changes its answer: ProbLib.py:31-43), 0.0 and the largest double below 1 among
+        # random ones -- the draw table decides in r's own domain and must agree with the reference's comparison in
+        # total * r's for every one of them
+        exp_t = orc.expand_table(probs)
+        thr_set = []
+        for ctx in list(exp_t)[:400]:
+            cum_r = exp_t[ctx][2]
+            thr_set.append(cum_r[:-1] / cum_r[-1])
+        thr_set = np.concatenate(thr_set) if thr_set else np.zeros(0)
+        ki, di = 1500, 24
+        u_inj = rng.integers(0, 2 ** 53, size=(ki, di)).astype(np.float64) * 2.0 ** -53
+        if len(thr_set):
+            near = thr_set[rng.integers(0, len(thr_set), size=(ki, di))]
+            step_u = rng.integers(-1, 2, size=(ki, di))
+            near = np.where(step_u < 0, np.nextafter(near, 0.0), np.where(step_u > 0, np.nextafter(near, 1.0), near))
+            u_inj = np.where(rng.random((ki, di)) < 0.45, near, u_inj)
+        edge = rng.random((ki, di))
+        u_inj = np.where(edge < 0.03, 0.0, np.where(edge > 0.97, 1.0 - 2.0 ** -53, u_inj))
+        u_inj = np.clip(u_inj, 0.0, 1.0 - 2.0 ** -53)
+        inj = m._dev.sample_injected(u_inj, sym_stride=20)
+        try:
+            m._dev.check()
+        except nv.NativeError as e:                              # (samples that need more than `di` draws: NaN on both sides)
+            assert e.code == nv.ERR_DIVERGED, e
+        want_i = cm.sample(ki, 0, uniforms=u_inj, stride=20)
+        gi, lost_i = inj["ml2p"].cpu().numpy(), np.isnan(want_i["ml2p"])
+        keep_i = np.flatnonzero(~lost_i)
+        ok6 = (np.array_equal(np.isnan(gi), lost_i) and np.array_equal(bits(gi[~lost_i]), bits(want_i["ml2p"][~lost_i]))
+               and np.array_equal(inj["draws"].cpu().numpy().astype(np.uint32)[keep_i], want_i["draws"][keep_i])
+               and np.array_equal(inj["len"].cpu().numpy().astype(np.uint32)[keep_i], want_i["len"][keep_i])
+               and m._flat.decode(inj["syms"].cpu().numpy()[keep_i], np.minimum(inj["len"].cpu().numpy()[keep_i], 20))
+               == cm.strings({"syms": want_i["syms"][keep_i], "len": np.minimum(want_i["len"][keep_i], 20)}))
+        ok = ok and ok6
         # MonteCarlo.sample(size, sampled_pwds) (MonteCarloParent.py:26-46): the dict of distinct sampled strings built
         # from the GPU's dedup (one row per distinct string reaches the host; strings longer than the kept stride are
         # replayed) against the one built from every sample of the C oracle, content and first-sampled order
@@ -360,7 +394,7 @@ def main():
             bad += 1
         print(f"case {c:3d} {what:18s} lines={len(lines):5d} alphabet={len(alpha):2d} samples={count:5d} "
               f"failed={cnt['failed']} indirect={cnt['indirect_draws']} sample={'ok' if ok else 'BAD'} "
-              f"score={'ok' if ok2 else 'BAD'} parse_file={len(want_p)} {'ok' if ok4 else 'BAD'} dedup={n_distinct} {'ok' if ok5 else 'BAD'} enumerated={len(want_e)} {'ok' if ok3 else 'BAD'}", flush=True)
+              f"score={'ok' if ok2 else 'BAD'} parse_file={len(want_p)} {'ok' if ok4 else 'BAD'} dedup={n_distinct} {'ok' if ok5 else 'BAD'} injected={len(keep_i)} {'ok' if ok6 else 'BAD'} enumerated={len(want_e)} {'ok' if ok3 else 'BAD'}", flush=True)
     print("ALL OK" if not bad else f"{bad} FAILED")
     sys.exit(1 if bad else 0)
 

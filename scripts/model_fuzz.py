@@ -228,6 +228,28 @@ def bpe_case(rng, c):
                       f"here ({gx[i]!r}, {got_s[i]!r}, {int(gd[i])} draws)", flush=True)
                 shown += 1
         print(f"   counters {cnt}; seed {sd}", flush=True)
+    # injected uniforms at the thresholds of the structures' row and of the terminal rows (see the character-level case)
+    rows = [o.grammars] + list(o.terminals.values())[:200]
+    thr_set = np.concatenate([r[2][:-1] / r[2][-1] for r in rows])
+    ki, di = 600, m._flat.max_segments + 1
+    u_inj = rng.integers(0, 2 ** 53, size=(ki, di)).astype(np.float64) * 2.0 ** -53
+    if len(thr_set):
+        near = thr_set[rng.integers(0, len(thr_set), size=(ki, di))]
+        step_u = rng.integers(-1, 2, size=(ki, di))
+        near = np.where(step_u < 0, np.nextafter(near, 0.0), np.where(step_u > 0, np.nextafter(near, 1.0), near))
+        u_inj = np.where(rng.random((ki, di)) < 0.5, near, u_inj)
+    edge = rng.random((ki, di))
+    u_inj = np.clip(np.where(edge < 0.03, 0.0, np.where(edge > 0.97, 1.0, u_inj)), 0.0, 1.0 - 2.0 ** -53)
+    inj = m._dev.sample_injected(u_inj, sym_stride=m._flat.max_segments)
+    m._dev.check()
+    inj_s = m._flat.decode_entries(inj["syms"].cpu().numpy(), inj["len"].cpu().numpy())
+    inj_x = inj["ml2p"].cpu().numpy()
+    ok3 = True
+    for i in range(ki):
+        it = iter(u_inj[i].tolist())
+        x, t = o.sample1(lambda: next(it))
+        ok3 = ok3 and bits([x])[0] == bits([inj_x[i]])[0] and t == inj_s[i]
+    ok = ok and ok3
     uniq = list(dict.fromkeys(want_s))[:1500]
     alphabet = "abcjABF019!@._~ é"
     mut = []
@@ -239,7 +261,7 @@ def bpe_case(rng, c):
     got, _parts = m.score_batch(pw)
     ok2 = np.array_equal(bits(got), bits([o.calc_ml2p(t) for t in pw]))
     return ok and ok2, (f"case {c:3d} bpe-pcfg structures={ns:2d}                 samples={count:5d} "
-                        f"sample={'ok' if ok else 'BAD'} score={'ok' if ok2 else 'BAD'}")
+                        f"sample={'ok' if ok else 'BAD'} injected={'ok' if ok3 else 'BAD'} score={'ok' if ok2 else 'BAD'}")
 
 
 def main():

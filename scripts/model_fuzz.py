@@ -50,6 +50,39 @@ def corpus(rng):
     return [words[i] for i in rng.choice(len(words), size=n, p=zw)], alpha
 
 
+def injected_check(rng, m, cm, exp_t, stride, drop=""):
+    """-> (samples that ended within the draws given, all equal?): injected uniforms at the rows' thresholds (see main)"""
+    thr_set = []
+    for ctx in list(exp_t)[:400]:
+        cum_r = exp_t[ctx][2]
+        thr_set.append(cum_r[:-1] / cum_r[-1])
+    thr_set = np.concatenate(thr_set) if thr_set else np.zeros(0)
+    ki, di = 1500, 24
+    u_inj = rng.integers(0, 2 ** 53, size=(ki, di)).astype(np.float64) * 2.0 ** -53
+    if len(thr_set):
+        near = thr_set[rng.integers(0, len(thr_set), size=(ki, di))]
+        step_u = rng.integers(-1, 2, size=(ki, di))
+        near = np.where(step_u < 0, np.nextafter(near, 0.0), np.where(step_u > 0, np.nextafter(near, 1.0), near))
+        u_inj = np.where(rng.random((ki, di)) < 0.45, near, u_inj)
+    edge = rng.random((ki, di))
+    u_inj = np.where(edge < 0.03, 0.0, np.where(edge > 0.97, 1.0 - 2.0 ** -53, u_inj))
+    u_inj = np.clip(u_inj, 0.0, 1.0 - 2.0 ** -53)
+    inj = m._dev.sample_injected(u_inj, sym_stride=stride)
+    try:
+        m._dev.check()
+    except nv.NativeError as e:                              # (samples that need more than `di` draws: NaN on both sides)
+        assert e.code == nv.ERR_DIVERGED, e
+    want_i = cm.sample(ki, 0, uniforms=u_inj, stride=stride)
+    gi, lost_i = inj["ml2p"].cpu().numpy(), np.isnan(want_i["ml2p"])
+    keep_i = np.flatnonzero(~lost_i)
+    same = (np.array_equal(np.isnan(gi), lost_i) and np.array_equal(bits(gi[~lost_i]), bits(want_i["ml2p"][~lost_i]))
+            and np.array_equal(inj["draws"].cpu().numpy().astype(np.uint32)[keep_i], want_i["draws"][keep_i])
+            and np.array_equal(inj["len"].cpu().numpy().astype(np.uint32)[keep_i], want_i["len"][keep_i])
+            and m._flat.decode(inj["syms"].cpu().numpy()[keep_i], np.minimum(inj["len"].cpu().numpy()[keep_i], stride))
+            == cm.strings({"syms": want_i["syms"][keep_i], "len": np.minimum(want_i["len"][keep_i], stride)}, drop=drop))
+    return len(keep_i), same
+
+
 def subword_corpus(rng):
     """lines of 1 .. 5 tab-separated tokens of 1 .. 4 characters: many passwords have several segmentations"""
     k = int(rng.integers(2, 12))
@@ -106,6 +139,8 @@ def subword_case(rng, c):
     got_s = m._flat.decode(res["syms"].cpu().numpy()[keep], np.minimum(res["len"].cpu().numpy()[keep], 24))
     want_s = cm.strings({"syms": want["syms"][keep], "len": np.minimum(want["len"][keep], 24)}, drop="\x00")
     ok = ok and got_s == want_s
+    n_inj, ok_inj = injected_check(rng, m, cm, orc.expand_table(probs), 24, drop="\x00")
+    ok = ok and ok_inj
     # (the DFS visits every segmentation, as the reference's does: the number of them grows like 1.9^length on a small
     # alphabet, and the Python oracle walks them one by one -- passwords of at most 14 characters here)
     test = [t for t in dict.fromkeys("".join(line.split("\t")) for line in lines) if len(t) <= 14][:250]
@@ -148,6 +183,8 @@ def v2_case(rng, c):
     got_s = m._flat.decode(res["syms"].cpu().numpy()[keep], np.minimum(res["len"].cpu().numpy()[keep], 24))
     want_s = cm.strings({"syms": want["syms"][keep], "len": np.minimum(want["len"][keep], 24)})
     ok = ok and got_s == want_s
+    n_inj, ok_inj = injected_check(rng, m, cm, orc.expand_table(probs), 24)
+    ok = ok and ok_inj
     return ok, (f"case {c:3d} v2 n={n}                             lines={len(lines):5d} samples={count:5d} "
                 f"lost={int(lost.sum())} sample={'ok' if ok else 'BAD'}")
 
@@ -350,35 +387,7 @@ def main():
         # bisect_right(cum, total * r) changes its answer: ProbLib.py:31-43), 0.0 and the largest double below 1 among
         # random ones -- the draw table decides in r's own domain and must agree with the reference's comparison in
         # total * r's for every one of them
-        exp_t = orc.expand_table(probs)
-        thr_set = []
-        for ctx in list(exp_t)[:400]:
-            cum_r = exp_t[ctx][2]
-            thr_set.append(cum_r[:-1] / cum_r[-1])
-        thr_set = np.concatenate(thr_set) if thr_set else np.zeros(0)
-        ki, di = 1500, 24
-        u_inj = rng.integers(0, 2 ** 53, size=(ki, di)).astype(np.float64) * 2.0 ** -53
-        if len(thr_set):
-            near = thr_set[rng.integers(0, len(thr_set), size=(ki, di))]
-            step_u = rng.integers(-1, 2, size=(ki, di))
-            near = np.where(step_u < 0, np.nextafter(near, 0.0), np.where(step_u > 0, np.nextafter(near, 1.0), near))
-            u_inj = np.where(rng.random((ki, di)) < 0.45, near, u_inj)
-        edge = rng.random((ki, di))
-        u_inj = np.where(edge < 0.03, 0.0, np.where(edge > 0.97, 1.0 - 2.0 ** -53, u_inj))
-        u_inj = np.clip(u_inj, 0.0, 1.0 - 2.0 ** -53)
-        inj = m._dev.sample_injected(u_inj, sym_stride=20)
-        try:
-            m._dev.check()
-        except nv.NativeError as e:                              # (samples that need more than `di` draws: NaN on both sides)
-            assert e.code == nv.ERR_DIVERGED, e
-        want_i = cm.sample(ki, 0, uniforms=u_inj, stride=20)
-        gi, lost_i = inj["ml2p"].cpu().numpy(), np.isnan(want_i["ml2p"])
-        keep_i = np.flatnonzero(~lost_i)
-        ok6 = (np.array_equal(np.isnan(gi), lost_i) and np.array_equal(bits(gi[~lost_i]), bits(want_i["ml2p"][~lost_i]))
-               and np.array_equal(inj["draws"].cpu().numpy().astype(np.uint32)[keep_i], want_i["draws"][keep_i])
-               and np.array_equal(inj["len"].cpu().numpy().astype(np.uint32)[keep_i], want_i["len"][keep_i])
-               and m._flat.decode(inj["syms"].cpu().numpy()[keep_i], np.minimum(inj["len"].cpu().numpy()[keep_i], 20))
-               == cm.strings({"syms": want_i["syms"][keep_i], "len": np.minimum(want_i["len"][keep_i], 20)}))
+        n_inj, ok6 = injected_check(rng, m, cm, orc.expand_table(probs), 20)
         ok = ok and ok6
         # MonteCarlo.sample(size, sampled_pwds) (MonteCarloParent.py:26-46): the dict of distinct sampled strings built
         # from the GPU's dedup (one row per distinct string reaches the host; strings longer than the kept stride are
@@ -416,7 +425,7 @@ def main():
             bad += 1
         print(f"case {c:3d} {what:18s} lines={len(lines):5d} alphabet={len(alpha):2d} samples={count:5d} "
               f"failed={cnt['failed']} indirect={cnt['indirect_draws']} sample={'ok' if ok else 'BAD'} "
-              f"score={'ok' if ok2 else 'BAD'} parse_file={len(want_p)} {'ok' if ok4 else 'BAD'} dedup={n_distinct} {'ok' if ok5 else 'BAD'} injected={len(keep_i)} {'ok' if ok6 else 'BAD'} enumerated={len(want_e)} {'ok' if ok3 else 'BAD'}", flush=True)
+              f"score={'ok' if ok2 else 'BAD'} parse_file={len(want_p)} {'ok' if ok4 else 'BAD'} dedup={n_distinct} {'ok' if ok5 else 'BAD'} injected={n_inj} {'ok' if ok6 else 'BAD'} enumerated={len(want_e)} {'ok' if ok3 else 'BAD'}", flush=True)
     print("ALL OK" if not bad else f"{bad} FAILED")
     sys.exit(1 if bad else 0)
 

@@ -44,6 +44,10 @@ for c in range(cases):
         keys, kind = tr.score_like(g, n, distinct=distinct), f"score-like/{distinct}"
     keys = keys.contiguous().to(dev)
     keys = torch.where(torch.isfinite(keys) & (keys >= 0), keys, torch.full_like(keys, 1.5))
+    if int(torch.randint(0, 8, (1,), generator=g)) == 0:     # certain strings among the samples: -log2 p = +0.0, many times
+        zero = torch.rand(n, generator=g) < float(torch.rand(1, generator=g))
+        keys = torch.where(zero.to(dev), torch.zeros_like(keys), keys)
+        kind = f"{kind} with zeros"
     buffers = None
     if int(torch.randint(0, 2, (1,), generator=g)):
         size = 1 << max(10, (n - 1).bit_length())
